@@ -1,0 +1,259 @@
+// TEST INFRASTRUCTURE ONLY -- never linked into or called by the product path.
+//
+// Harness around the *real* reference (autch/sac v0.0.4), compiled from the sources where
+// they lie under /root/reference/src (see oracle/Makefile; nothing is copied into this repo).
+// It exists so that the CPU restatement in oracle/sac_oracle.c -- and through it the HIP path --
+// can be pinned against the reference's own private hot-path entry points:
+//   FrameCoder::PredictStereoFrame  (src/codec.cpp:154-214)
+//   FrameCoder::GetCost             (src/codec.cpp:341-352)
+//   FrameCoder::Optimize            (src/codec.cpp:354-408)
+//   CostGolomb::Calc                (src/codec.cpp:315-339)
+//   StereoHigh/StereoNormal         (src/profile.cpp:46-186)
+//   LMSADA2 / LPC3 / LPC2 / RLS     (src/pred/nlms.h:96, src/pred/lpc.h:172,254, src/pred/rls.cpp)
+//
+// The reference keeps these private and defines CostGolomb inside codec.cpp, so this TU
+// includes codec.cpp itself after `#define private public` (layout is unchanged by that).
+// Only available in the build container (the reference does not travel to the GPU box as
+// source; the built oracle/_ref/libsacref.so does).
+#include <vector>
+#include <string>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <random>
+#include <ctime>
+#include <iostream>
+#include <sstream>
+#include <algorithm>
+#include <fstream>
+#include <iomanip>
+#include <chrono>
+#include <cstring>
+
+#define private public
+#define protected public
+#include "codec.cpp"
+#undef private
+#undef protected
+
+namespace {
+struct CoutMute {
+  std::streambuf *old;
+  std::ostringstream sink;
+  CoutMute() { old = std::cout.rdbuf(sink.rdbuf()); }
+  ~CoutMute() { std::cout.rdbuf(old); }
+};
+
+void load_frame(FrameCoder &fc, const int32_t *s0, const int32_t *s1, int total) {
+  for (int i = 0; i < total; i++) { fc.samples[0][i] = s0[i]; fc.samples[1][i] = s1[i]; }
+  fc.SetNumSamples(total);
+  // FrameCoder::Predict (codec.cpp:448-452): remap tables are built before prediction
+  for (int ch = 0; ch < 2; ch++) {
+    fc.framestats[ch].mymap.Reset();
+    fc.framestats[ch].mymap.Analyse(&(fc.samples[ch][0]), total);
+  }
+}
+void set_coefs(SacProfile &p, const double *coefs, int ncoef) {
+  if (!coefs) return;
+  for (int i = 0; i < ncoef && i < (int)p.coefs.size(); i++) p.coefs[i].vdef = coefs[i];
+}
+}  // namespace
+
+extern "C" {
+
+float ref_rsqrt(float x) { return rsqrt(x); }
+
+int ref_cholesky_test() { Cholesky c(4); return c.Test() ? 1 : 0; }
+
+// Base profile table (codec.cpp:8-30): writes ncoef x {vmin,vmax,vdef}, returns ncoef.
+int ref_base_profile(int profile, double *out) {
+  FrameCoder fc(2, 16, profile);
+  int n = (int)fc.baseprofile.coefs.size();
+  for (int i = 0; i < n; i++) {
+    out[3 * i] = fc.baseprofile.coefs[i].vmin;
+    out[3 * i + 1] = fc.baseprofile.coefs[i].vmax;
+    out[3 * i + 2] = fc.baseprofile.coefs[i].vdef;
+  }
+  return n;
+}
+
+// PredictStereoFrame(profile, 0, 1, from, n) on a frame holding `total` samples.
+// coefs==NULL -> base profile. maxbpn[4] = {maxbpn0, maxbpn1, maxbpn_map0, maxbpn_map1}.
+void ref_predict_stereo_frame(int profile, const double *coefs, int ncoef, const int32_t *s0,
+                              const int32_t *s1, int total, int from, int n, int32_t *e0,
+                              int32_t *e1, int32_t *u0, int32_t *u1, int32_t *m0, int32_t *m1,
+                              int *maxbpn) {
+  CoutMute mute;
+  FrameCoder fc(2, total, profile);
+  load_frame(fc, s0, s1, total);
+  SacProfile p = fc.baseprofile;
+  set_coefs(p, coefs, ncoef);
+  fc.PredictStereoFrame(p, 0, 1, from, n);
+  for (int i = 0; i < n; i++) {
+    if (e0) e0[i] = fc.error[0][i];
+    if (e1) e1[i] = fc.error[1][i];
+    if (u0) u0[i] = fc.s2u_error[0][i];
+    if (u1) u1[i] = fc.s2u_error[1][i];
+    if (m0) m0[i] = fc.s2u_error_map[0][i];
+    if (m1) m1[i] = fc.s2u_error_map[1][i];
+  }
+  if (maxbpn) {
+    maxbpn[0] = fc.framestats[0].maxbpn;
+    maxbpn[1] = fc.framestats[1].maxbpn;
+    maxbpn[2] = fc.framestats[0].maxbpn_map;
+    maxbpn[3] = fc.framestats[1].maxbpn_map;
+  }
+}
+
+// CostGolomb::Calc with the carried running mean exposed (state_inout).
+double ref_cost_golomb(const int32_t *buf, int n, double *state_inout) {
+  CostGolomb c;
+  c.mean_err.sum = *state_inout;
+  double r = c.Calc(buf, n);
+  *state_inout = c.mean_err.sum;
+  return r;
+}
+
+double ref_cost_meanrms(const int32_t *buf, int n) {
+  CostMeanRMS c;
+  return c.Calc(buf, n);
+}
+
+// The real FrameCoder::Optimize on the base profile ("ref+opt": codec.cpp:455-456 un-commented).
+// best[ncoef] receives the selected vdef values.
+int ref_optimize(int profile, const int32_t *s0, const int32_t *s1, int numsamples, double *best) {
+  CoutMute mute;
+  FrameCoder fc(2, numsamples, profile);
+  load_frame(fc, s0, s1, numsamples);
+  SacProfile opt = fc.baseprofile;
+  if (opt.coefs.size() < 8) return -1;  // Optimize indexes coefs[0..7] unconditionally (codec.cpp:389)
+  fc.Optimize(opt);
+  for (size_t i = 0; i < opt.coefs.size(); i++) best[i] = opt.coefs[i].vdef;
+  return (int)opt.coefs.size();
+}
+
+// Same schedule as Optimize (codec.cpp:354-408) driven through the real GetCost with one
+// CostGolomb instance, recording every (coef, x, cost) triple. ncoef_loop lets non-high
+// profiles run the documented deviation (loop over coefs.size() instead of 8).
+// trace: rows of 3 doubles {coef(-1 for the baseline call), x, cost}; returns number of rows.
+int ref_optimize_trace(int profile, const int32_t *s0, const int32_t *s1, int numsamples,
+                       int ncoef_loop, double *best, double *trace, int max_rows) {
+  CoutMute mute;
+  FrameCoder fc(2, numsamples, profile);
+  load_frame(fc, s0, s1, numsamples);
+  SacProfile prof = fc.baseprofile;
+  int samples_to_optimize = numsamples / 8;
+  int start = (numsamples - samples_to_optimize) / 2;
+  CostGolomb CostFunc;
+  int rows = 0;
+  double best_cost = fc.GetCost(prof, &CostFunc, 0, prof.coefs[0].vdef, start, samples_to_optimize);
+  if (rows < max_rows) { trace[3 * rows] = -1; trace[3 * rows + 1] = prof.coefs[0].vdef; trace[3 * rows + 2] = best_cost; rows++; }
+  for (int i = 0; i < ncoef_loop; i++) {
+    double best_x = prof.coefs[i].vdef;
+    double x = prof.coefs[i].vmin;
+    double xinc = (prof.coefs[i].vmax - prof.coefs[i].vmin) / 10.;
+    while (x <= prof.coefs[i].vmax) {
+      double cost = fc.GetCost(prof, &CostFunc, i, x, start, samples_to_optimize);
+      if (rows < max_rows) { trace[3 * rows] = i; trace[3 * rows + 1] = x; trace[3 * rows + 2] = cost; rows++; }
+      if (cost < best_cost) { best_x = x; best_cost = cost; }
+      x += xinc;
+    }
+    prof.coefs[i].vdef = best_x;
+  }
+  for (size_t i = 0; i < prof.coefs.size(); i++) best[i] = prof.coefs[i].vdef;
+  return rows;
+}
+
+// Per-stage trace of StereoHigh (profile.cpp:113-186) / StereoNormal (:46-111).
+// p_out[t][ch][k] (k<nst) = stage predictions, v_out[t][ch][k] = stage inputs after CalcError.
+// nst = 5 (high) or 4 (normal). Steps exactly as Predict(int32..)+Update() do.
+void ref_cascade_trace(int profile, const double *coefs, int ncoef, const int32_t *s0,
+                       const int32_t *s1, int n, double *p_out, double *v_out, int32_t *e0,
+                       int32_t *e1) {
+  CoutMute mute;
+  FrameCoder fc(2, 16, profile);
+  SacProfile prof = fc.baseprofile;
+  set_coefs(prof, coefs, ncoef);
+  if (profile == 2) {
+    StereoHigh sp(prof, fc.framestats);
+    for (int t = 0; t < n; t++) {
+      int32_t q0 = (int32_t)round(sp.Predict(0, 1));
+      for (int k = 0; k < 5; k++) p_out[(t * 2 + 0) * 5 + k] = sp.p[k];
+      sp.CalcError(0, s0[t]);
+      int32_t q1 = (int32_t)round(sp.Predict(1, 0));
+      for (int k = 0; k < 5; k++) p_out[(t * 2 + 1) * 5 + k] = sp.p[k];
+      sp.CalcError(1, s1[t]);
+      for (int ch = 0; ch < 2; ch++)
+        for (int k = 0; k < 5; k++) v_out[(t * 2 + ch) * 5 + k] = sp.val[ch][k];
+      if (e0) e0[t] = s0[t] - q0;
+      if (e1) e1[t] = s1[t] - q1;
+      sp.Update();
+    }
+  } else if (profile == 1) {
+    StereoNormal sp(prof, fc.framestats);
+    for (int t = 0; t < n; t++) {
+      int32_t q0 = (int32_t)round(sp.Predict(0, 1));
+      for (int k = 0; k < 4; k++) p_out[(t * 2 + 0) * 4 + k] = sp.p[k];
+      sp.CalcError(0, s0[t]);
+      int32_t q1 = (int32_t)round(sp.Predict(1, 0));
+      for (int k = 0; k < 4; k++) p_out[(t * 2 + 1) * 4 + k] = sp.p[k];
+      sp.CalcError(1, s1[t]);
+      for (int ch = 0; ch < 2; ch++)
+        for (int k = 0; k < 4; k++) v_out[(t * 2 + ch) * 4 + k] = sp.val[ch][k];
+      if (e0) e0[t] = s0[t] - q0;
+      if (e1) e1[t] = s1[t] - q1;
+      sp.Update();
+    }
+  }
+}
+
+// One stereo pair of LMSADA2(S,D,mu1,mu2) stages driven as the cascades drive them:
+//   p0 = lms[0].Predict(x1[t-1]) ; p1 = lms[1].Predict(x0[t]) ; lms[c].Update(xc[t]).
+void ref_lms_pair(int S, int D, double mu1, double mu2, const double *x0, const double *x1, int n,
+                  double *p0, double *p1) {
+  std::vector<LMSADA2> lms(2, LMSADA2(S, D, mu1, mu2));
+  double prev1 = 0.;
+  for (int t = 0; t < n; t++) {
+    p0[t] = lms[0].Predict(prev1);
+    p1[t] = lms[1].Predict(x0[t]);
+    lms[0].Update(x0[t]);
+    lms[1].Update(x1[t]);
+    prev1 = x1[t];
+  }
+}
+
+// One stereo pair of LPC3(alpha,16,8,8,500) stages driven as StereoHigh/Normal drive them.
+void ref_lpc3_pair(double alpha, const int32_t *s0, const int32_t *s1, int n, double *p0, double *p1) {
+  CoutMute mute;
+  std::vector<LPC3> lpc(2, LPC3(alpha, 16, 8, 8, 500));
+  double prev1 = 0.;
+  for (int t = 0; t < n; t++) {
+    p0[t] = lpc[0].Predict(prev1);
+    p1[t] = lpc[1].Predict((double)s0[t]);
+    lpc[0].Update((double)s0[t]);
+    lpc[1].Update((double)s1[t]);
+    prev1 = (double)s1[t];
+  }
+}
+
+// RLS(n,alpha) mixer: p[t] = Predict(pv[t][0..n)); Update(val[t]).
+void ref_rls_run(int n, double alpha, const double *pv, const double *val, int len, double *p) {
+  RLS r(n, alpha);
+  std::vector<double> v(n);
+  for (int t = 0; t < len; t++) {
+    for (int i = 0; i < n; i++) v[i] = pv[t * n + i];
+    p[t] = r.Predict(v);
+    r.Update(val[t]);
+  }
+}
+
+// Remap::Map (coder/map.cpp:141-152) after Analyse over src[0..n).
+void ref_remap_map(const int32_t *src, int n, const int32_t *pred, const int32_t *err, int m, int32_t *out) {
+  Remap r;
+  r.Reset();
+  std::vector<int32_t> tmp(src, src + n);
+  r.Analyse(tmp.data(), n);
+  for (int i = 0; i < m; i++) out[i] = r.Map(pred[i], err[i]);
+}
+
+}  // extern "C"

@@ -1,0 +1,98 @@
+"""Generate tests/golden/*.npz from the REAL reference (oracle/_ref/libsacref.so).
+
+Run in the build container only (needs /root/reference to build oracle/_ref):
+    make -C oracle ref && python tests/golden/make_golden.py
+The fixtures are data only: seeded synthetic inputs (re-generated from sac_amd.synth at test
+time, and also stored) and the reference's outputs. They pin the behaviour of the x86
+`rsqrtss` of the CPU they were generated on (Intel Xeon here) -- the probed table travels with
+them and every test that compares against a fixture runs with THAT table.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from oracle_lib import Oracle, Ref  # noqa: E402
+from sac_amd.synth import stereo_clip  # noqa: E402
+
+
+def main():
+    ref = Ref()
+    orc = Oracle()
+    tab, bits = orc.probe_rsqrt()
+    assert bits >= 0
+    # sanity: the table reproduces the native instruction the reference just used
+    rs = np.random.RandomState(0)
+    xs = np.abs(rs.randn(20000).astype(np.float32)) * np.float32(10.0) ** rs.randint(-3, 12, 20000).astype(np.float32) + np.float32(1e-3)
+    orc.set_rsqrt_table(tab, bits)
+    for x in xs[:5000]:
+        assert np.float32(orc.rsqrt(float(x))).tobytes() == np.float32(ref.rsqrt(float(x))).tobytes()
+    np.savez_compressed(os.path.join(HERE, "rsqrt_table.npz"), tab=tab, bits=np.int32(bits))
+
+    out = {}
+    # --- PredictStereoFrame, 3 profiles, seed 11, 4096 samples out of a 6000-sample frame
+    L, R = stereo_clip(11, 6000)
+    out["pred_L"], out["pred_R"] = L, R
+    for prof in (0, 1, 2):
+        d = ref.predict(prof, L, R, frm=0, n=4096, maps=True)
+        for k, v in d.items():
+            out[f"pred{prof}_{k}"] = v
+        d = ref.predict(prof, L, R, frm=1500, n=2000, maps=True)  # window not at frame start
+        for k, v in d.items():
+            out[f"predw{prof}_{k}"] = v
+    # non-default coefficients (high)
+    cf = np.array([0.9899, 2e-5, 3e-6, 3e-4, 2e-4, 1e-3, 0.02, 0.9995])
+    out["predc_coefs"] = cf
+    d = ref.predict(2, L, R, frm=0, n=3000, coefs=cf)
+    out["predc_e0"], out["predc_e1"] = d["e0"], d["e1"]
+    # --- per-stage traces, first 96 samples
+    for prof in (1, 2):
+        p, v, e0, e1 = ref.cascade_trace(prof, L[:96], R[:96])
+        out[f"trace{prof}_p"], out[f"trace{prof}_v"] = p, v
+    # --- stage-level drivers
+    x0 = (rs.randn(3000) * 300.0)
+    x1 = 0.5 * x0 + rs.randn(3000) * 200.0
+    out["lms_x0"], out["lms_x1"] = x0, x1
+    for (S, D, m1, m2) in [(1280, 640, 1e-5, 5e-6), (256, 128, 5e-4, 1e-4), (32, 16, 3e-3, 3e-3), (8, 4, 0.01, 0.01)]:
+        p0, p1 = ref.lms_pair(S, D, m1, m2, x0, x1)
+        out[f"lms{S}_p0"], out[f"lms{S}_p1"] = p0, p1
+    p0, p1 = ref.lpc3_pair(0.997, L[:3000], R[:3000])
+    out["lpc3_p0"], out["lpc3_p1"] = p0, p1
+    pv = rs.randn(2000, 4) * 100.0
+    val = rs.randn(2000) * 100.0
+    out["rls_pv"], out["rls_val"] = pv, val
+    out["rls4_p"] = ref.rls_run(4, 0.998, pv, val)
+    out["rls3_p"] = ref.rls_run(3, 0.998, np.ascontiguousarray(pv[:, :3]), val)
+    # --- CostGolomb with carried state
+    e = rs.randint(-3000, 3000, 5000).astype(np.int32)
+    out["cost_e"] = e
+    c1, s1 = ref.cost_golomb(e[:2500], 0.0)
+    c2, s2 = ref.cost_golomb(e[2500:], s1)
+    out["cost_vals"] = np.array([c1, s1, c2, s2, ref.cost_meanrms(e)])
+    # --- Optimize on one 8192-sample frame (window 1024): trace of 84 GetCost calls + winners
+    Lo, Ro = stereo_clip(12, 8192)
+    out["opt_L"], out["opt_R"] = Lo, Ro
+    best, trace = ref.optimize_trace(2, Lo, Ro)
+    best2, n = ref.optimize(2, Lo, Ro)
+    assert n == 8 and np.array_equal(best, best2), "trace replay deviates from FrameCoder::Optimize"
+    out["opt_best"], out["opt_trace"] = best, trace
+    # second frame, larger (window 2048)
+    Lo2, Ro2 = stereo_clip(13, 16384)
+    out["opt2_L"], out["opt2_R"] = Lo2, Ro2
+    best, trace = ref.optimize_trace(2, Lo2, Ro2)
+    out["opt2_best"], out["opt2_trace"] = best, trace
+    # normal profile with the documented deviation (loop over its 6 coefs)
+    best, trace = ref.optimize_trace(1, Lo, Ro, ncoef_loop=6)
+    out["optn_best"], out["optn_trace"] = best[:6], trace
+    # base profiles
+    for prof in (0, 1, 2):
+        out[f"base{prof}"] = ref.base_profile(prof)
+    np.savez_compressed(os.path.join(HERE, "golden.npz"), **out)
+    print("wrote", len(out), "arrays")
+
+
+if __name__ == "__main__":
+    main()

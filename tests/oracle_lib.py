@@ -1,0 +1,195 @@
+"""ctypes bindings for the test oracles (TEST INFRASTRUCTURE ONLY).
+
+  ORACLE : oracle/_build/liboracle.so  -- the C restatement (oracle/sac_oracle.c)
+  REF    : oracle/_ref/libsacref.so    -- the real reference + harness (may be absent)
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_ORACLE_SO = os.path.join(ROOT, "oracle", "_build", "liboracle.so")
+_REF_SO = os.path.join(ROOT, "oracle", "_ref", "libsacref.so")
+
+i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+vp = C.c_void_p
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(vp)
+
+
+def build_oracle():
+    if not os.path.exists(_ORACLE_SO) or os.path.getmtime(_ORACLE_SO) < os.path.getmtime(
+            os.path.join(ROOT, "oracle", "sac_oracle.c")):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "oracle"])
+    return _ORACLE_SO
+
+
+class _Lib:
+    """Common python-level API over either library (prefix 'oracle_' or 'ref_')."""
+
+    def __init__(self, path, prefix):
+        self.lib = C.CDLL(path)
+        self.pre = prefix
+        L = self.lib
+        f = getattr(L, prefix + "predict_stereo_frame")
+        f.restype = None if prefix == "ref_" else C.c_int
+        g = getattr(L, prefix + "cost_golomb")
+        g.restype = C.c_double
+        g.argtypes = [i32p, C.c_int, C.POINTER(C.c_double)]
+        g = getattr(L, prefix + "cost_meanrms")
+        g.restype = C.c_double
+        g.argtypes = [i32p, C.c_int]
+        getattr(L, prefix + "rsqrt").restype = C.c_float
+        getattr(L, prefix + "rsqrt").argtypes = [C.c_float]
+
+    def base_profile(self, profile):
+        out = np.zeros(24, dtype=np.float64)
+        n = getattr(self.lib, self.pre + "base_profile")(C.c_int(profile), _ptr(out))
+        return out[:3 * n].reshape(n, 3).copy()
+
+    def predict(self, profile, s0, s1, frm=0, n=None, coefs=None, maps=False):
+        s0 = np.ascontiguousarray(s0, dtype=np.int32)
+        s1 = np.ascontiguousarray(s1, dtype=np.int32)
+        total = len(s0)
+        if n is None:
+            n = total - frm
+        e0 = np.zeros(n, np.int32); e1 = np.zeros(n, np.int32)
+        u0 = np.zeros(n, np.int32); u1 = np.zeros(n, np.int32)
+        m0 = np.zeros(n, np.int32) if maps else None
+        m1 = np.zeros(n, np.int32) if maps else None
+        mb = np.zeros(4, np.int32) if maps else None
+        cf = None if coefs is None else np.ascontiguousarray(coefs, dtype=np.float64)
+        f = getattr(self.lib, self.pre + "predict_stereo_frame")
+        if self.pre == "ref_":
+            f(C.c_int(profile), _ptr(cf), C.c_int(0 if cf is None else len(cf)), _ptr(s0), _ptr(s1),
+              C.c_int(total), C.c_int(frm), C.c_int(n), _ptr(e0), _ptr(e1), _ptr(u0), _ptr(u1),
+              _ptr(m0), _ptr(m1), _ptr(mb))
+        else:
+            f(C.c_int(profile), _ptr(cf), _ptr(s0), _ptr(s1), C.c_int(total), C.c_int(frm),
+              C.c_int(n), _ptr(e0), _ptr(e1), _ptr(u0), _ptr(u1), _ptr(m0), _ptr(m1), _ptr(mb))
+        return dict(e0=e0, e1=e1, u0=u0, u1=u1, m0=m0, m1=m1, maxbpn=mb)
+
+    def cost_golomb(self, buf, state=0.0):
+        buf = np.ascontiguousarray(buf, dtype=np.int32)
+        st = C.c_double(state)
+        r = getattr(self.lib, self.pre + "cost_golomb")(buf, len(buf), C.byref(st))
+        return r, st.value
+
+    def cost_meanrms(self, buf):
+        buf = np.ascontiguousarray(buf, dtype=np.int32)
+        return getattr(self.lib, self.pre + "cost_meanrms")(buf, len(buf))
+
+    def rsqrt(self, x):
+        return getattr(self.lib, self.pre + "rsqrt")(C.c_float(x))
+
+    def lms_pair(self, S, D, mu1, mu2, x0, x1):
+        x0 = np.ascontiguousarray(x0, dtype=np.float64); x1 = np.ascontiguousarray(x1, dtype=np.float64)
+        n = len(x0)
+        p0 = np.zeros(n); p1 = np.zeros(n)
+        getattr(self.lib, self.pre + "lms_pair")(C.c_int(S), C.c_int(D), C.c_double(mu1), C.c_double(mu2),
+                                                 _ptr(x0), _ptr(x1), C.c_int(n), _ptr(p0), _ptr(p1))
+        return p0, p1
+
+    def lpc3_pair(self, alpha, s0, s1):
+        s0 = np.ascontiguousarray(s0, dtype=np.int32); s1 = np.ascontiguousarray(s1, dtype=np.int32)
+        n = len(s0)
+        p0 = np.zeros(n); p1 = np.zeros(n)
+        getattr(self.lib, self.pre + "lpc3_pair")(C.c_double(alpha), _ptr(s0), _ptr(s1), C.c_int(n), _ptr(p0), _ptr(p1))
+        return p0, p1
+
+    def rls_run(self, n, alpha, pv, val):
+        pv = np.ascontiguousarray(pv, dtype=np.float64); val = np.ascontiguousarray(val, dtype=np.float64)
+        ln = len(val)
+        p = np.zeros(ln)
+        getattr(self.lib, self.pre + "rls_run")(C.c_int(n), C.c_double(alpha), _ptr(pv), _ptr(val), C.c_int(ln), _ptr(p))
+        return p
+
+    def cascade_trace(self, profile, s0, s1, coefs=None):
+        s0 = np.ascontiguousarray(s0, dtype=np.int32); s1 = np.ascontiguousarray(s1, dtype=np.int32)
+        n = len(s0)
+        nst = 5 if profile == 2 else 4
+        p = np.zeros((n, 2, nst)); v = np.zeros((n, 2, nst))
+        e0 = np.zeros(n, np.int32); e1 = np.zeros(n, np.int32)
+        cf = None if coefs is None else np.ascontiguousarray(coefs, dtype=np.float64)
+        f = getattr(self.lib, self.pre + "cascade_trace")
+        if self.pre == "ref_":
+            f(C.c_int(profile), _ptr(cf), C.c_int(0 if cf is None else len(cf)), _ptr(s0), _ptr(s1), C.c_int(n),
+              _ptr(p), _ptr(v), _ptr(e0), _ptr(e1))
+        else:
+            f(C.c_int(profile), _ptr(cf), _ptr(s0), _ptr(s1), C.c_int(n), _ptr(p), _ptr(v), _ptr(e0), _ptr(e1))
+        return p, v, e0, e1
+
+    def remap_map(self, src, pred, err):
+        src = np.ascontiguousarray(src, dtype=np.int32)
+        pred = np.ascontiguousarray(pred, dtype=np.int32); err = np.ascontiguousarray(err, dtype=np.int32)
+        out = np.zeros(len(pred), np.int32)
+        getattr(self.lib, self.pre + "remap_map")(_ptr(src), C.c_int(len(src)), _ptr(pred), _ptr(err),
+                                                  C.c_int(len(pred)), _ptr(out))
+        return out
+
+
+class Oracle(_Lib):
+    def __init__(self):
+        super().__init__(build_oracle(), "oracle_")
+        self.lib.oracle_rsqrt_native.restype = C.c_float
+        self.lib.oracle_rsqrt_native.argtypes = [C.c_float]
+        self._tab = None
+
+    def set_rsqrt_table(self, tab, bits):
+        """tab=None -> native rsqrtss of this CPU."""
+        if tab is None:
+            self._tab = None
+            self.lib.oracle_set_rsqrt_table(None, 0)
+        else:
+            self._tab = np.ascontiguousarray(tab, dtype=np.float32)
+            assert len(self._tab) == 2 << bits
+            self.lib.oracle_set_rsqrt_table(_ptr(self._tab), C.c_int(bits))
+
+    def probe_rsqrt(self, cap=1 << 16):
+        tab = np.zeros(cap, np.float32)
+        bits = self.lib.oracle_probe_rsqrt(_ptr(tab), C.c_int(cap))
+        if bits < 0:
+            return None, -1
+        return tab[:2 << bits].copy(), bits
+
+    def cholesky_kat(self):
+        return bool(self.lib.oracle_cholesky_kat())
+
+    def optimize(self, profile, s0, s1, prof=None, ncoef_loop=8, max_rows=128):
+        s0 = np.ascontiguousarray(s0, dtype=np.int32); s1 = np.ascontiguousarray(s1, dtype=np.int32)
+        best = np.zeros(8); trace = np.zeros((max_rows, 3))
+        pf = None if prof is None else np.ascontiguousarray(prof, dtype=np.float64)
+        rows = self.lib.oracle_optimize(C.c_int(profile), _ptr(pf), C.c_int(ncoef_loop), _ptr(s0), _ptr(s1),
+                                        C.c_int(len(s0)), _ptr(best), _ptr(trace), C.c_int(max_rows))
+        return best, trace[:rows].copy()
+
+
+class Ref(_Lib):
+    def __init__(self):
+        super().__init__(_REF_SO, "ref_")
+
+    def cholesky_kat(self):
+        return bool(self.lib.ref_cholesky_test())
+
+    def optimize(self, profile, s0, s1):
+        s0 = np.ascontiguousarray(s0, dtype=np.int32); s1 = np.ascontiguousarray(s1, dtype=np.int32)
+        best = np.zeros(8)
+        n = self.lib.ref_optimize(C.c_int(profile), _ptr(s0), _ptr(s1), C.c_int(len(s0)), _ptr(best))
+        return best[:max(n, 0)], n
+
+    def optimize_trace(self, profile, s0, s1, ncoef_loop=8, max_rows=128):
+        s0 = np.ascontiguousarray(s0, dtype=np.int32); s1 = np.ascontiguousarray(s1, dtype=np.int32)
+        best = np.zeros(8); trace = np.zeros((max_rows, 3))
+        rows = self.lib.ref_optimize_trace(C.c_int(profile), _ptr(s0), _ptr(s1), C.c_int(len(s0)),
+                                           C.c_int(ncoef_loop), _ptr(best), _ptr(trace), C.c_int(max_rows))
+        return best, trace[:rows].copy()
+
+
+def have_ref():
+    return os.path.exists(_REF_SO)

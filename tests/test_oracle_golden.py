@@ -1,0 +1,95 @@
+"""CPU: the oracle (oracle/sac_oracle.c) against the golden vectors generated from the real
+reference (tests/golden/make_golden.py). Bit-exact everywhere (integer residuals, and FP64
+stage outputs compared as raw bits)."""
+import numpy as np
+import pytest
+
+from sac_amd.synth import stereo_clip
+
+
+def same_bits(a, b):
+    a = np.ascontiguousarray(a); b = np.ascontiguousarray(b)
+    return a.shape == b.shape and a.tobytes() == b.tobytes()
+
+
+def test_synth_is_deterministic(golden):
+    L, R = stereo_clip(11, 6000)
+    assert np.array_equal(L, golden["pred_L"]) and np.array_equal(R, golden["pred_R"])
+    L, R = stereo_clip(12, 8192)
+    assert np.array_equal(L, golden["opt_L"]) and np.array_equal(R, golden["opt_R"])
+
+
+def test_cholesky_kat(oracle):
+    # reference: Cholesky::Test (src/math/cholesky.cpp:3-14)
+    assert oracle.cholesky_kat()
+
+
+def test_base_profiles(oracle, golden):
+    for prof in (0, 1, 2):
+        assert same_bits(oracle.base_profile(prof), golden[f"base{prof}"])
+
+
+@pytest.mark.parametrize("prof", [0, 1, 2])
+def test_predict_stereo_frame(oracle, golden, prof):
+    L, R = golden["pred_L"], golden["pred_R"]
+    d = oracle.predict(prof, L, R, frm=0, n=4096, maps=True)
+    for k, v in d.items():
+        assert np.array_equal(v, golden[f"pred{prof}_{k}"]), k
+    d = oracle.predict(prof, L, R, frm=1500, n=2000, maps=True)
+    for k, v in d.items():
+        assert np.array_equal(v, golden[f"predw{prof}_{k}"]), k
+
+
+def test_predict_custom_coefs(oracle, golden):
+    d = oracle.predict(2, golden["pred_L"], golden["pred_R"], frm=0, n=3000, coefs=golden["predc_coefs"])
+    assert np.array_equal(d["e0"], golden["predc_e0"]) and np.array_equal(d["e1"], golden["predc_e1"])
+
+
+@pytest.mark.parametrize("prof", [1, 2])
+def test_stage_traces(oracle, golden, prof):
+    p, v, _, _ = oracle.cascade_trace(prof, golden["pred_L"][:96], golden["pred_R"][:96])
+    assert same_bits(p, golden[f"trace{prof}_p"]) and same_bits(v, golden[f"trace{prof}_v"])
+
+
+@pytest.mark.parametrize("S,D,m1,m2", [(1280, 640, 1e-5, 5e-6), (256, 128, 5e-4, 1e-4), (32, 16, 3e-3, 3e-3), (8, 4, 0.01, 0.01)])
+def test_lms_pair(oracle, golden, S, D, m1, m2):
+    p0, p1 = oracle.lms_pair(S, D, m1, m2, golden["lms_x0"], golden["lms_x1"])
+    assert same_bits(p0, golden[f"lms{S}_p0"]) and same_bits(p1, golden[f"lms{S}_p1"])
+
+
+def test_lpc3_pair(oracle, golden):
+    p0, p1 = oracle.lpc3_pair(0.997, golden["pred_L"][:3000], golden["pred_R"][:3000])
+    assert same_bits(p0, golden["lpc3_p0"]) and same_bits(p1, golden["lpc3_p1"])
+
+
+def test_rls(oracle, golden):
+    assert same_bits(oracle.rls_run(4, 0.998, golden["rls_pv"], golden["rls_val"]), golden["rls4_p"])
+    assert same_bits(oracle.rls_run(3, 0.998, np.ascontiguousarray(golden["rls_pv"][:, :3]), golden["rls_val"]), golden["rls3_p"])
+
+
+def test_cost_golomb_carried_state(oracle, golden):
+    e = golden["cost_e"]
+    c1, s1 = oracle.cost_golomb(e[:2500], 0.0)
+    c2, s2 = oracle.cost_golomb(e[2500:], s1)
+    assert same_bits(np.array([c1, s1, c2, s2, oracle.cost_meanrms(e)]), golden["cost_vals"])
+    assert oracle.cost_golomb(e[:0], 1.5) == (0.0, 1.5)  # empty input: cost 0, state untouched
+
+
+def test_optimize_trace(oracle, golden):
+    # FrameCoder::Optimize (src/codec.cpp:354-408): 84 GetCost calls, 8 selected values
+    best, trace = oracle.optimize(2, golden["opt_L"], golden["opt_R"])
+    assert len(trace) == 84
+    assert same_bits(trace, golden["opt_trace"]) and same_bits(best, golden["opt_best"])
+
+
+def test_optimize_trace_normal_profile(oracle, golden):
+    best, trace = oracle.optimize(1, golden["opt_L"], golden["opt_R"], ncoef_loop=6)
+    assert same_bits(trace, golden["optn_trace"]) and same_bits(best[:6], golden["optn_best"])
+
+
+def test_ragged_and_empty(oracle):
+    L, R = stereo_clip(3, 50)
+    d = oracle.predict(2, L, R, frm=0, n=0)
+    assert len(d["e0"]) == 0
+    d = oracle.predict(2, L, R, frm=49, n=1)
+    assert d["e0"][0] == L[49] and d["e1"][0] == R[49]  # fresh state predicts 0
