@@ -1,0 +1,116 @@
+/* libsacopt -- MI355X (gfx950) implementation of sac's encoder-side parameter optimizer and
+ * stereo predictor cascade, behind a plain C ABI.
+ *
+ * The reference (autch/sac v0.0.4) has no plugin/FFI layer: the seam is a set of private
+ * C++ members of FrameCoder. Each entry point below replaces one of them
+ * (reference file:line relative to the reference tree) and keeps its argument meaning.
+ * All functions return 0 on success, non-zero on error (sacopt_last_error() has the text);
+ * nothing throws across the ABI. Sample / residual pointers may be host or device
+ * pointers (detected with hipPointerGetAttributes); host buffers are staged through
+ * internal device buffers. One context per GPU; a context is not thread-safe, different
+ * contexts are independent.
+ *
+ * There is NO CPU fallback: every entry point fails if no gfx950 device is usable.
+ */
+#ifndef SACOPT_H
+#define SACOPT_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sacopt_ctx sacopt_ctx;
+
+#define SACOPT_PROFILE_FAST   0 /* StereoFast   src/profile.cpp:3-43   (1 coef)  */
+#define SACOPT_PROFILE_NORMAL 1 /* StereoNormal src/profile.cpp:46-111 (6 coefs) */
+#define SACOPT_PROFILE_HIGH   2 /* StereoHigh   src/profile.cpp:113-186 (8 coefs) */
+#define SACOPT_MAX_COEFS 8
+
+/* One frame of one stereo pair (FrameCoder::samples[0..1], src/codec.h:29). */
+typedef struct {
+  const int32_t *s0;  /* channel 0 samples, numsamples entries (host or device) */
+  const int32_t *s1;  /* channel 1 samples */
+  int32_t numsamples; /* FrameCoder::numsamples (src/codec.h:48) */
+} sacopt_frame;
+
+/* Residual outputs of PredictStereoFrame for one frame; any pointer may be NULL.
+ * (FrameCoder::error / s2u_error / s2u_error_map and framestats[].maxbpn{,_map},
+ *  src/codec.cpp:165-211.) Host or device pointers. */
+typedef struct {
+  int32_t *err0, *err1;     /* error[ch][0..n)          */
+  int32_t *s2u0, *s2u1;     /* s2u_error[ch][0..n)      */
+  int32_t *map0, *map1;     /* s2u_error_map[ch][0..n)  */
+  int32_t maxbpn[4];        /* out: maxbpn0, maxbpn1, maxbpn_map0, maxbpn_map1 (host memory, in the struct) */
+} sacopt_residuals;
+
+/* ---- context -------------------------------------------------------------------------- */
+/* The LMS stages use the x86 `rsqrtss` approximation (src/pred/nlms.h:34-57), whose value is
+ * CPU-specific. rsqrt_tab/rsqrt_bits give the table to emulate: 2^(bits+1) floats indexed by
+ * (exponent-field parity << bits) | top `bits` mantissa bits (see sacopt_probe_rsqrt).
+ * rsqrt_tab == NULL: probe the CPU this process runs on (what the reference would use here). */
+int sacopt_create(int device, const float *rsqrt_tab, int rsqrt_bits, sacopt_ctx **out);
+void sacopt_destroy(sacopt_ctx *ctx);
+const char *sacopt_last_error(const sacopt_ctx *ctx); /* ctx may be NULL: error of a failed create */
+
+/* Host-only: probe this CPU's rsqrtss. tab must hold `cap` floats; returns bits >= 0, or -1 if
+ * the table model does not hold for this CPU or cap < 2^(bits+1). */
+int sacopt_probe_rsqrt(float *tab, int cap);
+
+/* SacProfile tables of FrameCoder::FrameCoder (src/codec.cpp:8-30): writes ncoef x
+ * {vmin, vmax, vdef}; returns ncoef (0 for an unknown profile). */
+int sacopt_base_profile(int profile, double *out);
+
+/* ---- FrameCoder::PredictStereoFrame(profile, 0, 1, from, n)   src/codec.cpp:154-214 ------ */
+/* For every frame f: fresh predictor state, predict samples [from[f], from[f]+n[f]) with
+ * coefs[f*ncoef .. ) and write the residuals. from/n == NULL means the whole frame.
+ * Remap tables are built over the whole frame as FrameCoder::Predict does (codec.cpp:448-452)
+ * when map outputs are requested. */
+int sacopt_predict_stereo_frames(sacopt_ctx *ctx, int profile, int nframes, const sacopt_frame *frames,
+                                 const int32_t *from, const int32_t *n, const double *coefs,
+                                 sacopt_residuals *out);
+
+/* ---- FrameCoder::GetCost  src/codec.cpp:341-352  (+ CostGolomb::Calc :315-339) ------------- */
+/* Evaluates, for every frame, `ncand` candidate coefficient vectors (cand_coefs[(f*ncand+c)*ncoef..])
+ * over the window [from[f], from[f]+n[f]) and returns costs[f*ncand+c] =
+ * (Calc(err0)+Calc(err1))/2. The CostGolomb running mean is carried from candidate to candidate
+ * in index order exactly as one CostGolomb instance would (codec.cpp:364); cost_state[f]
+ * (in/out, may be NULL = start from 0) is that running mean. */
+int sacopt_get_costs(sacopt_ctx *ctx, int profile, int nframes, const sacopt_frame *frames,
+                     const int32_t *from, const int32_t *n, int ncand, const double *cand_coefs,
+                     double *costs, double *cost_state);
+
+/* ---- FrameCoder::Optimize  src/codec.cpp:354-408 --------------------------------------------- */
+/* Coordinate grid search over the first `ncoef_loop` coefficients (the reference hard-codes 8,
+ * codec.cpp:389; pass the profile's coefficient count for fast/normal). prof = ncoef x
+ * {vmin,vmax,vdef} shared by all frames (NULL = base profile). Outputs (host memory):
+ *   best[f*ncoef + i]   the selected vdef values,
+ *   trace[(f*max_rows + r)*3 ..] optional rows {coef (-1 = baseline call), x, cost} in call order,
+ *   rows[f]             optional number of GetCost calls made (84 for the high profile). */
+int sacopt_optimize_frames(sacopt_ctx *ctx, int profile, int nframes, const sacopt_frame *frames,
+                           const double *prof, int ncoef_loop, double *best, double *trace,
+                           int max_rows, int32_t *rows);
+
+/* ---- CostGolomb::Calc / CostMeanRMS::Calc on caller-supplied residuals (src/codec.cpp:302-339) - */
+int sacopt_cost_golomb(sacopt_ctx *ctx, const int32_t *buf, int n, double *state_inout, double *cost);
+int sacopt_cost_meanrms(sacopt_ctx *ctx, const int32_t *buf, int n, double *cost);
+
+/* ---- stage-level entry points (used by the parity tests to pin single kernels) --------------- */
+/* Stereo pair of LMSADA2(S,D,mu1,mu2) (src/pred/nlms.h:96-139) driven as the cascades drive them.
+ * Supported (S,D): (1280,640) (256,128) (32,16) (8,4). x/p are host or device doubles. */
+int sacopt_lms_pair(sacopt_ctx *ctx, int S, int D, double mu1, double mu2, const double *x0,
+                    const double *x1, int n, double *p0, double *p1);
+/* Stereo pair of LPC3(alpha,16,8,8,500) (src/pred/lpc.h:172-228). */
+int sacopt_lpc3_pair(sacopt_ctx *ctx, double alpha, const int32_t *s0, const int32_t *s1, int n,
+                     double *p0, double *p1);
+/* RLS(nst,alpha) mixer (src/pred/rls.cpp:61-108): p[t] = Predict(pv[t][0..nst)); Update(val[t]). */
+int sacopt_rls_run(sacopt_ctx *ctx, int nst, double alpha, const double *pv, const double *val,
+                   int len, double *p);
+
+/* Timing of the last call, measured with HIP events on the library's own stream:
+ * total device ms and ms spent in the dominant (LMS stage) kernel, plus its launch count. */
+int sacopt_last_timing(const sacopt_ctx *ctx, double *total_ms, double *lms_ms, int *lms_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,49 @@
+// Job descriptors shared by the kernels (kernels.hip) and the host orchestration (sacopt.cpp).
+// One descriptor = one (frame, candidate) chain for one stage kernel; arrays of descriptors are
+// uploaded once per launch and indexed by blockIdx.x.
+#ifndef SACOPT_JOBS_H
+#define SACOPT_JOBS_H
+#include <stdint.h>
+
+#define LMS_CHUNK 512     // samples staged into the LDS history ring at a time
+#define RSQ_LDS_MAX 4096  // rsqrt table entries kept in LDS (bits <= 11)
+
+struct LmsJob {
+  const double *x[2];  // stage inputs val[ch][k]      (n doubles each)
+  double *p[2];        // stage predictions p[k]
+  double *xn[2];       // next stage inputs val[ch][k+1] = x - p (may be NULL)
+  double mu1, mu2;
+  int32_t n, pad;
+};
+
+struct LpcJob {
+  const int32_t *s[2];  // window samples (already offset by `from`)
+  double *p[2];         // LPC3: p[0]
+  double *x1[2];        // LPC3: val[ch][1] = v - p[0]
+  int32_t *e[2];        // LPC2 (fast profile): error[ch]
+  int32_t *u[2];        // LPC2: s2u_error[ch]
+  int32_t *umax;        // LPC2: [2] max s2u
+  double alpha;
+  int32_t n, pad;
+};
+
+struct MixJob {
+  const int32_t *s[2];
+  const double *p0[2];
+  const double *pk[4][2];  // LMS stage predictions p[1..NS]
+  const double *x1[2];     // val[ch][1] (RLS update target, profile.cpp:184)
+  int32_t *e[2];           // error[ch]           (may be NULL)
+  int32_t *u[2];           // s2u_error[ch]       (may be NULL)
+  int32_t *umax;           // [2] max s2u          (may be NULL)
+  double alpha;
+  int32_t n, pad;
+};
+
+struct CostJob {
+  const int32_t *const *bufs;  // nbuf residual buffers in CostGolomb call order (cand0 ch0, cand0 ch1, ...)
+  double *costs;               // nbuf/2 outputs: (Calc(ch0)+Calc(ch1))/2
+  double *state;               // carried running mean (in/out), may be NULL
+  int32_t n, nbuf;  // nbuf < 0: single-buffer mode, costs[0] = Calc(bufs[0])
+};
+
+#endif

@@ -1,0 +1,805 @@
+// libsacopt host side: C ABI (include/sacopt.h) + stage scheduling on one HIP stream.
+//
+// Scheduling model: the cascade is feed-forward between stages, so a candidate
+// evaluation is a chain of stage kernels (LPC3 -> LMS.. -> mixer) and a stage's output depends
+// only on the coefficients of the stages up to it. Stage outputs are memoised per frame on that
+// coefficient prefix: the coordinate search of FrameCoder::Optimize (src/codec.cpp:354-408)
+// changes one coefficient per round, so every round re-runs only the stages downstream of it
+// (bit-identical to the reference, which recomputes everything: src/codec.cpp:341-352).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/sacopt.h"
+#include "jobs.h"
+
+extern "C" {
+int sacopt_launch_lms(int S, int D, const LmsJob *jobs, int njobs, const float *tab, int bits, hipStream_t st);
+int sacopt_launch_lpc3(const LpcJob *jobs, int njobs, hipStream_t st);
+int sacopt_launch_lpc2(const LpcJob *jobs, int njobs, hipStream_t st);
+int sacopt_launch_mix(int ns, const MixJob *jobs, int njobs, hipStream_t st);
+int sacopt_launch_cost(const CostJob *jobs, int njobs, const int *pow2_bits, hipStream_t st);
+int sacopt_launch_meanrms(const int32_t *e, int n, double *out, hipStream_t st);
+int sacopt_launch_rls(int ns, const double *pv, const double *val, int len, double alpha, double *p, hipStream_t st);
+}
+
+static thread_local std::string g_create_error;
+
+struct sacopt_ctx {
+  int device = 0;
+  hipStream_t st = nullptr;
+  float *d_tab = nullptr;
+  int bits = 0;
+  int *d_pow2 = nullptr;
+  std::string err;
+  // bump arena (device)
+  char *arena = nullptr;
+  size_t cap = 0, used = 0;
+  // timing of the last call
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> lms_ev;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  double total_ms = 0, lms_ms = 0;
+  int lms_launches = 0;
+};
+
+#define HIPCK(ctx, call)                                                                          \
+  do {                                                                                            \
+    hipError_t e_ = (call);                                                                       \
+    if (e_ != hipSuccess) {                                                                       \
+      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                             \
+      return 1;                                                                                   \
+    }                                                                                             \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------ rsqrtss
+static float rsqrt_native(float x) {  // src/pred/nlms.h:34-57
+  float r;
+  __asm__ __volatile__("movss %1, %%xmm0\n rsqrtss %%xmm0, %%xmm1\n movss %%xmm1, %0\n" : "=m"(r) : "m"(x) : "xmm0", "xmm1");
+  return r;
+}
+static float rsqrt_from_table(const float *tab, int bits, float x) {
+  uint32_t u;
+  memcpy(&u, &x, 4);
+  const uint32_t e = (u >> 23) & 0xff, mant = u & 0x7fffff, par = e & 1;
+  const uint32_t idx = (par << bits) | (bits ? (mant >> (23 - bits)) : 0);
+  uint32_t tb;
+  memcpy(&tb, &tab[idx], 4);
+  const int q = ((int)e - (par ? 127 : 128)) / 2;
+  tb = (uint32_t)((int32_t)tb - (q << 23));
+  float r;
+  memcpy(&r, &tb, 4);
+  return r;
+}
+extern "C" int sacopt_probe_rsqrt(float *tab, int cap) {
+  const uint32_t NM = 1u << 23;
+  std::vector<uint32_t> out(2 * (size_t)NM);
+  for (uint32_t par = 0; par < 2; par++) {
+    const uint32_t e = par ? 127 : 128;
+    for (uint32_t m = 0; m < NM; m++) {
+      const uint32_t u = (e << 23) | m;
+      float x, r;
+      memcpy(&x, &u, 4);
+      r = rsqrt_native(x);
+      memcpy(&out[par * NM + m], &r, 4);
+    }
+  }
+  int bits = -1;
+  for (int k = 0; k <= 23 && bits < 0; k++) {
+    const uint32_t mask = ~((1u << (23 - k)) - 1) & (NM - 1);
+    bool ok = true;
+    for (uint32_t par = 0; par < 2 && ok; par++)
+      for (uint32_t m = 0; m < NM; m++)
+        if (out[par * NM + m] != out[par * NM + (m & mask)]) { ok = false; break; }
+    if (ok) bits = k;
+  }
+  if (bits < 0 || (2 << bits) > cap) return -1;
+  for (uint32_t par = 0; par < 2; par++)
+    for (uint32_t i = 0; i < (1u << bits); i++) memcpy(&tab[(par << bits) | i], &out[par * NM + (i << (23 - bits))], 4);
+  for (uint32_t e = 1; e < 255; e++)  // exponent-scale invariance
+    for (uint32_t i = 0; i < (1u << bits); i++)
+      for (int f = 0; f < 3; f++) {
+        const uint32_t low = (1u << (23 - bits)) - 1;
+        const uint32_t m = (i << (23 - bits)) | (f == 0 ? 0 : f == 1 ? low : (low >> 1));
+        const uint32_t u = (e << 23) | m;
+        float x, a, b;
+        memcpy(&x, &u, 4);
+        a = rsqrt_native(x);
+        b = rsqrt_from_table(tab, bits, x);
+        if (memcmp(&a, &b, 4)) return -1;
+      }
+  return bits;
+}
+
+// ------------------------------------------------------------------------------------------ profiles
+struct StageDesc { int S, D, c1, c2; };
+struct ProfDesc {
+  int type, ncoef, nlms;
+  StageDesc lms[4];
+  int cmix;        // coefficient index of the RLS alpha
+  int nprefix[6];  // coefs that determine the output of stage s (0 = LPC, 1..nlms = LMS, nlms+1 = mixer)
+  int stage_of_coef[8];
+};
+static bool get_prof(int type, ProfDesc *p) {
+  memset(p, 0, sizeof(*p));
+  p->type = type;
+  if (type == SACOPT_PROFILE_HIGH) {  // StereoHigh ctor, src/profile.cpp:113-124
+    p->ncoef = 8; p->nlms = 4;
+    p->lms[0] = {1280, 640, 1, 2}; p->lms[1] = {256, 128, 3, 4}; p->lms[2] = {32, 16, 5, 5}; p->lms[3] = {8, 4, 6, 6};
+    p->cmix = 7;
+    const int np[6] = {1, 3, 5, 6, 7, 8};
+    memcpy(p->nprefix, np, sizeof(np));
+    const int sc[8] = {0, 1, 1, 2, 2, 3, 4, 5};
+    memcpy(p->stage_of_coef, sc, sizeof(sc));
+  } else if (type == SACOPT_PROFILE_NORMAL) {  // StereoNormal ctor, src/profile.cpp:46-55
+    p->ncoef = 6; p->nlms = 3;
+    p->lms[0] = {256, 128, 1, 2}; p->lms[1] = {32, 16, 3, 3}; p->lms[2] = {8, 4, 4, 4};
+    p->cmix = 5;
+    const int np[6] = {1, 3, 4, 5, 6, 0};
+    memcpy(p->nprefix, np, sizeof(np));
+    const int sc[8] = {0, 1, 1, 2, 3, 4, 0, 0};
+    memcpy(p->stage_of_coef, sc, sizeof(sc));
+  } else if (type == SACOPT_PROFILE_FAST) {  // StereoFast ctor, src/profile.cpp:3-8
+    p->ncoef = 1; p->nlms = 0; p->cmix = -1;
+    p->nprefix[0] = 1;
+  } else return false;
+  return true;
+}
+
+extern "C" int sacopt_base_profile(int profile, double *out) {  // src/codec.cpp:8-30
+  static const double fast[1][3] = {{0.99, 0.999, 0.996}};
+  static const double normal[6][3] = {{0.99, 0.9999, 0.998}, {0.000001, 0.001, 0.0004}, {0.000001, 0.001, 0.0001},
+                                      {0.00001, 0.01, 0.003}, {0.0001, 0.1, 0.01},       {0.99, 0.9999, 0.998}};
+  static const double high[8][3] = {{0.98, 0.9999, 0.997},     {0.0000001, 0.0001, 0.00001}, {0.0000001, 0.0001, 0.000005},
+                                    {0.000001, 0.001, 0.0005}, {0.000001, 0.001, 0.0001},    {0.0001, 0.01, 0.003},
+                                    {0.001, 0.1, 0.01},        {0.99, 0.9999, 0.998}};
+  const double *src;
+  int n;
+  if (profile == 0) { src = &fast[0][0]; n = 1; }
+  else if (profile == 1) { src = &normal[0][0]; n = 6; }
+  else if (profile == 2) { src = &high[0][0]; n = 8; }
+  else return 0;
+  for (int i = 0; i < 3 * n; i++) out[i] = src[i];
+  return n;
+}
+
+// ------------------------------------------------------------------------------------------ context
+extern "C" const char *sacopt_last_error(const sacopt_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+extern "C" int sacopt_create(int device, const float *rsqrt_tab, int rsqrt_bits, sacopt_ctx **out) {
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_create_error = "no HIP device available (libsacopt has no CPU fallback)"; return 1; }
+  if (device < 0 || device >= ndev) { g_create_error = "device index out of range"; return 1; }
+  hipDeviceProp_t pr;
+  if (hipGetDeviceProperties(&pr, device) != hipSuccess) { g_create_error = "hipGetDeviceProperties failed"; return 1; }
+  if (strncmp(pr.gcnArchName, "gfx950", 6) != 0) { g_create_error = std::string("device is ") + pr.gcnArchName + ", libsacopt is built for gfx950 only"; return 1; }
+  std::vector<float> tab;
+  int bits = rsqrt_bits;
+  if (!rsqrt_tab) {
+    tab.resize(RSQ_LDS_MAX);
+    bits = sacopt_probe_rsqrt(tab.data(), RSQ_LDS_MAX);
+    if (bits < 0) { g_create_error = "host rsqrtss does not fit the parity x top-k-mantissa table model (k <= 11)"; return 1; }
+  } else {
+    if (bits < 0 || (2 << bits) > RSQ_LDS_MAX) { g_create_error = "rsqrt_bits out of range (0..11)"; return 1; }
+    tab.assign(rsqrt_tab, rsqrt_tab + (2 << bits));
+  }
+  sacopt_ctx *c = new sacopt_ctx;
+  c->device = device;
+  c->bits = bits;
+  auto fail = [&](const char *what) { g_create_error = what; delete c; return 1; };
+  if (hipSetDevice(device) != hipSuccess) return fail("hipSetDevice failed");
+  if (hipStreamCreate(&c->st) != hipSuccess) return fail("hipStreamCreate failed");
+  if (hipMalloc(&c->d_tab, sizeof(float) * (2 << bits)) != hipSuccess) return fail("hipMalloc(table) failed");
+  if (hipMemcpy(c->d_tab, tab.data(), sizeof(float) * (2 << bits), hipMemcpyHostToDevice) != hipSuccess) return fail("table upload failed");
+  int pw[32];
+  for (int k = 0; k < 31; k++) pw[k] = (int)ceil(log((double)(1 << k)) / log(2));  // codec.cpp:329 with THIS host's libm
+  pw[31] = 31;
+  if (hipMalloc(&c->d_pow2, sizeof(pw)) != hipSuccess) return fail("hipMalloc failed");
+  if (hipMemcpy(c->d_pow2, pw, sizeof(pw), hipMemcpyHostToDevice) != hipSuccess) return fail("upload failed");
+  if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) return fail("hipEventCreate failed");
+  *out = c;
+  return 0;
+}
+
+extern "C" void sacopt_destroy(sacopt_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->st) (void)hipStreamSynchronize(c->st);
+  for (auto &p : c->lms_ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->arena) (void)hipFree(c->arena);
+  if (c->d_tab) (void)hipFree(c->d_tab);
+  if (c->d_pow2) (void)hipFree(c->d_pow2);
+  if (c->st) (void)hipStreamDestroy(c->st);
+  delete c;
+}
+
+extern "C" int sacopt_last_timing(const sacopt_ctx *c, double *total_ms, double *lms_ms, int *lms_launches) {
+  if (!c) return 1;
+  if (total_ms) *total_ms = c->total_ms;
+  if (lms_ms) *lms_ms = c->lms_ms;
+  if (lms_launches) *lms_launches = c->lms_launches;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------ helpers
+static int arena_reserve(sacopt_ctx *c, size_t bytes) {
+  c->used = 0;
+  if (bytes <= c->cap) return 0;
+  if (c->arena) { HIPCK(c, hipStreamSynchronize(c->st)); HIPCK(c, hipFree(c->arena)); c->arena = nullptr; c->cap = 0; }
+  HIPCK(c, hipMalloc(&c->arena, bytes));
+  c->cap = bytes;
+  return 0;
+}
+template <class T>
+static T *arena_alloc(sacopt_ctx *c, size_t count) {
+  const size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
+  if (c->used + bytes > c->cap) return nullptr;
+  T *p = reinterpret_cast<T *>(c->arena + c->used);
+  c->used += bytes;
+  return p;
+}
+static bool is_device_ptr(const void *p) {
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return a.type == hipMemoryTypeDevice;
+}
+template <class T>
+static int upload(sacopt_ctx *c, const std::vector<T> &h, T **d) {
+  *d = arena_alloc<T>(c, h.size() ? h.size() : 1);
+  if (!*d) { c->err = "device arena exhausted"; return 1; }
+  if (h.size()) HIPCK(c, hipMemcpyAsync(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, c->st));
+  return 0;
+}
+static int begin_call(sacopt_ctx *c) {
+  HIPCK(c, hipSetDevice(c->device));
+  c->err.clear();
+  for (auto &p : c->lms_ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+  c->lms_ev.clear();
+  c->total_ms = c->lms_ms = 0;
+  c->lms_launches = 0;
+  return 0;
+}
+static int end_timing(sacopt_ctx *c) {
+  HIPCK(c, hipEventRecord(c->ev1, c->st));
+  HIPCK(c, hipStreamSynchronize(c->st));
+  float ms = 0;
+  HIPCK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  c->total_ms = ms;
+  for (auto &p : c->lms_ev) {
+    HIPCK(c, hipEventElapsedTime(&ms, p.first, p.second));
+    c->lms_ms += ms;
+  }
+  c->lms_launches = (int)c->lms_ev.size();
+  return 0;
+}
+
+// A frame window staged on the device
+struct DevFrame {
+  const int32_t *s[2];  // device, whole frame
+  int numsamples, from, n;
+};
+
+// Outputs of one stage for one memo key
+struct StageBuf {
+  double *p[2] = {nullptr, nullptr};
+  double *xn[2] = {nullptr, nullptr};
+  int32_t *e[2] = {nullptr, nullptr};
+  int32_t *u[2] = {nullptr, nullptr};
+  int32_t *umax = nullptr;
+};
+struct Chain {
+  int frame;
+  double coefs[SACOPT_MAX_COEFS];
+  StageBuf sb[6];
+};
+typedef std::map<std::string, StageBuf> Memo;
+
+static std::string memo_key(int frame, int stage, const double *coefs, int ncoef) {
+  std::string k(sizeof(int) * 2 + sizeof(double) * ncoef, '\0');
+  memcpy(&k[0], &frame, sizeof(int));
+  memcpy(&k[sizeof(int)], &stage, sizeof(int));
+  memcpy(&k[2 * sizeof(int)], coefs, sizeof(double) * ncoef);
+  return k;
+}
+
+// bytes of arena one chain needs for all its stages
+static size_t chain_bytes(const ProfDesc &pd, int n) {
+  const size_t nd = ((size_t)n * 8 + 255) & ~(size_t)255, ni = ((size_t)n * 4 + 255) & ~(size_t)255;
+  return (size_t)(pd.nlms + 1) * 4 * nd + 4 * ni + 256;
+}
+
+// Run all chains through the cascade, re-using memoised stage outputs. `want_u`: also write s2u.
+static int eval_chains(sacopt_ctx *c, const ProfDesc &pd, const std::vector<DevFrame> &fr, std::vector<Chain> &chains,
+                       Memo &memo) {
+  const int nstage = (pd.type == SACOPT_PROFILE_FAST) ? 1 : pd.nlms + 2;
+  for (int s = 0; s < nstage; s++) {
+    std::vector<int> todo;  // chain indices that own a new buffer at this stage
+    for (size_t ci = 0; ci < chains.size(); ci++) {
+      Chain &ch = chains[ci];
+      const std::string key = memo_key(ch.frame, s, ch.coefs, pd.nprefix[s]);
+      auto it = memo.find(key);
+      if (it != memo.end()) { ch.sb[s] = it->second; continue; }
+      const int n = fr[ch.frame].n;
+      StageBuf b;
+      const bool last = (s == nstage - 1);
+      if (!last) {
+        for (int k = 0; k < 2; k++) {
+          b.p[k] = arena_alloc<double>(c, n);
+          b.xn[k] = arena_alloc<double>(c, n);
+          if (!b.p[k] || !b.xn[k]) { c->err = "device arena exhausted"; return 1; }
+        }
+      } else {
+        for (int k = 0; k < 2; k++) {
+          b.e[k] = arena_alloc<int32_t>(c, n);
+          b.u[k] = arena_alloc<int32_t>(c, n);
+          if (!b.e[k] || !b.u[k]) { c->err = "device arena exhausted"; return 1; }
+        }
+        b.umax = arena_alloc<int32_t>(c, 2);
+        if (!b.umax) { c->err = "device arena exhausted"; return 1; }
+      }
+      ch.sb[s] = b;
+      memo[key] = b;
+      todo.push_back((int)ci);
+    }
+    if (todo.empty()) continue;
+    if (pd.type == SACOPT_PROFILE_FAST) {
+      std::vector<LpcJob> jobs;
+      for (int ci : todo) {
+        const Chain &ch = chains[ci];
+        const DevFrame &f = fr[ch.frame];
+        LpcJob j;
+        memset(&j, 0, sizeof(j));
+        for (int k = 0; k < 2; k++) { j.s[k] = f.s[k] + f.from; j.e[k] = ch.sb[0].e[k]; j.u[k] = ch.sb[0].u[k]; }
+        j.umax = ch.sb[0].umax;
+        j.alpha = ch.coefs[0];
+        j.n = f.n;
+        jobs.push_back(j);
+      }
+      LpcJob *dj;
+      if (upload(c, jobs, &dj)) return 1;
+      if (sacopt_launch_lpc2(dj, (int)jobs.size(), c->st)) { c->err = "k_lpc2 launch failed"; return 1; }
+    } else if (s == 0) {
+      std::vector<LpcJob> jobs;
+      for (int ci : todo) {
+        const Chain &ch = chains[ci];
+        const DevFrame &f = fr[ch.frame];
+        LpcJob j;
+        memset(&j, 0, sizeof(j));
+        for (int k = 0; k < 2; k++) { j.s[k] = f.s[k] + f.from; j.p[k] = ch.sb[0].p[k]; j.x1[k] = ch.sb[0].xn[k]; }
+        j.alpha = ch.coefs[0];
+        j.n = f.n;
+        j.pad = 0;
+        jobs.push_back(j);
+      }
+      LpcJob *dj;
+      if (upload(c, jobs, &dj)) return 1;
+      if (sacopt_launch_lpc3(dj, (int)jobs.size(), c->st)) { c->err = "k_lpc3 launch failed"; return 1; }
+    } else if (s <= pd.nlms) {
+      const StageDesc &sd = pd.lms[s - 1];
+      std::vector<LmsJob> jobs;
+      for (int ci : todo) {
+        const Chain &ch = chains[ci];
+        LmsJob j;
+        for (int k = 0; k < 2; k++) { j.x[k] = ch.sb[s - 1].xn[k]; j.p[k] = ch.sb[s].p[k]; j.xn[k] = ch.sb[s].xn[k]; }
+        j.mu1 = ch.coefs[sd.c1];
+        j.mu2 = ch.coefs[sd.c2];
+        j.n = fr[ch.frame].n;
+        j.pad = 0;
+        jobs.push_back(j);
+      }
+      LmsJob *dj;
+      if (upload(c, jobs, &dj)) return 1;
+      hipEvent_t a, b;
+      HIPCK(c, hipEventCreate(&a));
+      HIPCK(c, hipEventCreate(&b));
+      HIPCK(c, hipEventRecord(a, c->st));
+      if (sacopt_launch_lms(sd.S, sd.D, dj, (int)jobs.size(), c->d_tab, c->bits, c->st)) { c->err = "k_lms launch failed"; return 1; }
+      HIPCK(c, hipEventRecord(b, c->st));
+      c->lms_ev.push_back({a, b});
+    } else {
+      std::vector<MixJob> jobs;
+      for (int ci : todo) {
+        const Chain &ch = chains[ci];
+        const DevFrame &f = fr[ch.frame];
+        MixJob j;
+        memset(&j, 0, sizeof(j));
+        for (int k = 0; k < 2; k++) {
+          j.s[k] = f.s[k] + f.from;
+          j.p0[k] = ch.sb[0].p[k];
+          j.x1[k] = ch.sb[0].xn[k];
+          for (int q = 0; q < pd.nlms; q++) j.pk[q][k] = ch.sb[q + 1].p[k];
+          j.e[k] = ch.sb[s].e[k];
+          j.u[k] = ch.sb[s].u[k];
+        }
+        j.umax = ch.sb[s].umax;
+        j.alpha = ch.coefs[pd.cmix];
+        j.n = f.n;
+        jobs.push_back(j);
+      }
+      MixJob *dj;
+      if (upload(c, jobs, &dj)) return 1;
+      if (sacopt_launch_mix(pd.nlms, dj, (int)jobs.size(), c->st)) { c->err = "k_mix launch failed"; return 1; }
+    }
+  }
+  return 0;
+}
+
+// Stage input frames: device pointers are used in place, host pointers are copied into the arena.
+static int stage_frames(sacopt_ctx *c, int nframes, const sacopt_frame *frames, const int32_t *from, const int32_t *n,
+                        std::vector<DevFrame> &out) {
+  out.resize(nframes);
+  for (int f = 0; f < nframes; f++) {
+    DevFrame &d = out[f];
+    d.numsamples = frames[f].numsamples;
+    d.from = from ? from[f] : 0;
+    d.n = n ? n[f] : d.numsamples - d.from;
+    if (d.numsamples < 0 || d.from < 0 || d.n < 0 || d.from + d.n > d.numsamples) { c->err = "window outside frame"; return 1; }
+    const int32_t *src[2] = {frames[f].s0, frames[f].s1};
+    for (int k = 0; k < 2; k++) {
+      if (d.numsamples == 0) { d.s[k] = arena_alloc<int32_t>(c, 1); continue; }
+      if (!src[k]) { c->err = "null sample pointer"; return 1; }
+      if (is_device_ptr(src[k])) d.s[k] = src[k];
+      else {
+        int32_t *p = arena_alloc<int32_t>(c, d.numsamples);
+        if (!p) { c->err = "device arena exhausted"; return 1; }
+        HIPCK(c, hipMemcpyAsync(p, src[k], (size_t)d.numsamples * 4, hipMemcpyHostToDevice, c->st));
+        d.s[k] = p;
+      }
+    }
+  }
+  return 0;
+}
+
+static int copy_out(sacopt_ctx *c, void *dst, const void *src_dev, size_t bytes) {
+  if (!dst || !bytes) return 0;
+  HIPCK(c, hipMemcpyAsync(dst, src_dev, bytes, is_device_ptr(dst) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->st));
+  return 0;
+}
+
+static int ilog2(int v) { int nb = 0; while (v >>= 1) nb++; return nb; }  // MathUtils::iLog2 (utils.h:42-46)
+
+// ------------------------------------------------------------------------------------------ PredictStereoFrame
+extern "C" int sacopt_predict_stereo_frames(sacopt_ctx *c, int profile, int nframes, const sacopt_frame *frames,
+                                            const int32_t *from, const int32_t *n, const double *coefs,
+                                            sacopt_residuals *out) {
+  if (!c) return 1;
+  if (begin_call(c)) return 1;
+  ProfDesc pd;
+  if (!get_prof(profile, &pd)) { c->err = "unknown profile"; return 1; }
+  if (nframes < 0 || (nframes && (!frames || !out))) { c->err = "bad arguments"; return 1; }
+  double base[3 * SACOPT_MAX_COEFS];
+  sacopt_base_profile(profile, base);
+  size_t need = 1 << 20;
+  for (int f = 0; f < nframes; f++) {
+    const int nn = n ? n[f] : frames[f].numsamples - (from ? from[f] : 0);
+    need += chain_bytes(pd, nn > 0 ? nn : 0) + 2 * (((size_t)frames[f].numsamples * 4 + 255) & ~(size_t)255) + 4096;
+  }
+  if (arena_reserve(c, need)) return 1;
+  HIPCK(c, hipEventRecord(c->ev0, c->st));
+  std::vector<DevFrame> fr;
+  if (stage_frames(c, nframes, frames, from, n, fr)) return 1;
+  std::vector<Chain> chains(nframes);
+  for (int f = 0; f < nframes; f++) {
+    chains[f].frame = f;
+    for (int i = 0; i < pd.ncoef; i++) chains[f].coefs[i] = coefs ? coefs[(size_t)f * pd.ncoef + i] : base[3 * i + 2];
+  }
+  Memo memo;
+  if (eval_chains(c, pd, fr, chains, memo)) return 1;
+  const int last = (pd.type == SACOPT_PROFILE_FAST) ? 0 : pd.nlms + 1;
+  std::vector<int32_t> um(2 * (size_t)nframes);
+  for (int f = 0; f < nframes; f++) {
+    const StageBuf &b = chains[f].sb[last];
+    const size_t bytes = (size_t)fr[f].n * 4;
+    if (copy_out(c, out[f].err0, b.e[0], bytes) || copy_out(c, out[f].err1, b.e[1], bytes) ||
+        copy_out(c, out[f].s2u0, b.u[0], bytes) || copy_out(c, out[f].s2u1, b.u[1], bytes))
+      return 1;
+    HIPCK(c, hipMemcpyAsync(&um[2 * f], b.umax, 8, hipMemcpyDeviceToHost, c->st));
+  }
+  if (end_timing(c)) return 1;
+  for (int f = 0; f < nframes; f++) {
+    out[f].maxbpn[0] = ilog2(um[2 * f]);      // codec.cpp:207-208
+    out[f].maxbpn[1] = ilog2(um[2 * f + 1]);
+    out[f].maxbpn[2] = out[f].maxbpn[3] = -1;  // Remap::Map outputs: not produced yet
+    if (out[f].map0 || out[f].map1) { c->err = "s2u_error_map outputs are not implemented yet"; return 1; }
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------ GetCost / Optimize
+// Cost of `ncand` candidates per frame, in order, CostGolomb state carried (d_state[f]).
+static int cost_round(sacopt_ctx *c, const ProfDesc &pd, const std::vector<DevFrame> &fr, const std::vector<Chain> &chains,
+                      int ncand, double *d_state, std::vector<double> &costs_host) {
+  const int nframes = (int)fr.size();
+  const int last = (pd.type == SACOPT_PROFILE_FAST) ? 0 : pd.nlms + 1;
+  std::vector<const int32_t *> bufs(2 * (size_t)nframes * ncand);
+  for (int f = 0; f < nframes; f++)
+    for (int k = 0; k < ncand; k++) {
+      const Chain &ch = chains[(size_t)f * ncand + k];
+      bufs[2 * ((size_t)f * ncand + k)] = ch.sb[last].e[0];
+      bufs[2 * ((size_t)f * ncand + k) + 1] = ch.sb[last].e[1];
+    }
+  const int32_t **d_bufs;
+  if (upload(c, bufs, &d_bufs)) return 1;
+  double *d_costs = arena_alloc<double>(c, (size_t)nframes * ncand);
+  if (!d_costs) { c->err = "device arena exhausted"; return 1; }
+  std::vector<CostJob> jobs(nframes);
+  for (int f = 0; f < nframes; f++) {
+    jobs[f].bufs = d_bufs + 2 * (size_t)f * ncand;
+    jobs[f].costs = d_costs + (size_t)f * ncand;
+    jobs[f].state = d_state + f;
+    jobs[f].n = fr[f].n;
+    jobs[f].nbuf = 2 * ncand;
+  }
+  CostJob *dj;
+  if (upload(c, jobs, &dj)) return 1;
+  if (sacopt_launch_cost(dj, nframes, c->d_pow2, c->st)) { c->err = "k_cost launch failed"; return 1; }
+  costs_host.resize((size_t)nframes * ncand);
+  HIPCK(c, hipMemcpyAsync(costs_host.data(), d_costs, costs_host.size() * 8, hipMemcpyDeviceToHost, c->st));
+  HIPCK(c, hipStreamSynchronize(c->st));
+  return 0;
+}
+
+extern "C" int sacopt_get_costs(sacopt_ctx *c, int profile, int nframes, const sacopt_frame *frames, const int32_t *from,
+                                const int32_t *n, int ncand, const double *cand_coefs, double *costs, double *cost_state) {
+  if (!c) return 1;
+  if (begin_call(c)) return 1;
+  ProfDesc pd;
+  if (!get_prof(profile, &pd)) { c->err = "unknown profile"; return 1; }
+  if (nframes < 0 || ncand < 0 || (nframes && ncand && (!frames || !cand_coefs || !costs))) { c->err = "bad arguments"; return 1; }
+  if (!nframes || !ncand) return 0;
+  size_t need = 1 << 20;
+  for (int f = 0; f < nframes; f++) {
+    const int nn = n ? n[f] : frames[f].numsamples - (from ? from[f] : 0);
+    need += (size_t)ncand * chain_bytes(pd, nn > 0 ? nn : 0) + 2 * (((size_t)frames[f].numsamples * 4 + 255) & ~(size_t)255) + 4096 +
+            (size_t)ncand * 64;
+  }
+  if (arena_reserve(c, need)) return 1;
+  HIPCK(c, hipEventRecord(c->ev0, c->st));
+  std::vector<DevFrame> fr;
+  if (stage_frames(c, nframes, frames, from, n, fr)) return 1;
+  std::vector<Chain> chains((size_t)nframes * ncand);
+  for (int f = 0; f < nframes; f++)
+    for (int k = 0; k < ncand; k++) {
+      Chain &ch = chains[(size_t)f * ncand + k];
+      ch.frame = f;
+      memcpy(ch.coefs, cand_coefs + ((size_t)f * ncand + k) * pd.ncoef, sizeof(double) * pd.ncoef);
+    }
+  Memo memo;
+  if (eval_chains(c, pd, fr, chains, memo)) return 1;
+  std::vector<double> st(nframes, 0.);
+  if (cost_state) st.assign(cost_state, cost_state + nframes);
+  double *d_state;
+  if (upload(c, st, &d_state)) return 1;
+  std::vector<double> ch_costs;
+  if (cost_round(c, pd, fr, chains, ncand, d_state, ch_costs)) return 1;
+  memcpy(costs, ch_costs.data(), ch_costs.size() * 8);
+  if (cost_state) HIPCK(c, hipMemcpyAsync(cost_state, d_state, (size_t)nframes * 8, hipMemcpyDeviceToHost, c->st));
+  return end_timing(c);
+}
+
+extern "C" int sacopt_optimize_frames(sacopt_ctx *c, int profile, int nframes, const sacopt_frame *frames, const double *prof_in,
+                                      int ncoef_loop, double *best, double *trace, int max_rows, int32_t *rows_out) {
+  if (!c) return 1;
+  if (begin_call(c)) return 1;
+  ProfDesc pd;
+  if (!get_prof(profile, &pd)) { c->err = "unknown profile"; return 1; }
+  if (nframes < 0 || (nframes && (!frames || !best))) { c->err = "bad arguments"; return 1; }
+  if (ncoef_loop < 0 || ncoef_loop > pd.ncoef) { c->err = "ncoef_loop exceeds the profile's coefficient count (the reference would index past coefs[], codec.cpp:389)"; return 1; }
+  if (!nframes) return 0;
+  double prof[3 * SACOPT_MAX_COEFS];
+  sacopt_base_profile(profile, prof);
+  if (prof_in) memcpy(prof, prof_in, sizeof(double) * 3 * pd.ncoef);
+  // candidate grids, generated exactly as the reference loop does (codec.cpp:392-404)
+  std::vector<std::vector<double>> grid(ncoef_loop);
+  size_t total_cand = 1;
+  for (int i = 0; i < ncoef_loop; i++) {
+    double x = prof[3 * i];
+    const double xinc = (prof[3 * i + 1] - prof[3 * i]) / 10.;
+    while (x <= prof[3 * i + 1]) {
+      grid[i].push_back(x);
+      x += xinc;
+      if (grid[i].size() > 64) { c->err = "degenerate coefficient range (grid does not terminate)"; return 1; }
+    }
+    total_cand += grid[i].size();
+  }
+  // windows (codec.cpp:356-359)
+  std::vector<int32_t> from(nframes), wn(nframes);
+  size_t need = 1 << 20;
+  for (int f = 0; f < nframes; f++) {
+    wn[f] = frames[f].numsamples / 8;
+    from[f] = (frames[f].numsamples - wn[f]) / 2;
+    need += total_cand * (chain_bytes(pd, wn[f]) + 256) + 2 * (((size_t)frames[f].numsamples * 4 + 255) & ~(size_t)255) + 8192;
+  }
+  if (arena_reserve(c, need)) return 1;
+  HIPCK(c, hipEventRecord(c->ev0, c->st));
+  std::vector<DevFrame> fr;
+  if (stage_frames(c, nframes, frames, from.data(), wn.data(), fr)) return 1;
+  std::vector<double> st(nframes, 0.);  // one CostGolomb instance per Optimize call (codec.cpp:364)
+  double *d_state;
+  if (upload(c, st, &d_state)) return 1;
+
+  std::vector<std::vector<double>> cur(nframes, std::vector<double>(pd.ncoef));
+  for (int f = 0; f < nframes; f++)
+    for (int i = 0; i < pd.ncoef; i++) cur[f][i] = prof[3 * i + 2];
+  std::vector<double> best_cost(nframes);
+  std::vector<int> rows(nframes, 0);
+  Memo memo;
+  auto add_row = [&](int f, double coef, double x, double cost) {
+    if (trace && rows[f] < max_rows) {
+      double *r = trace + ((size_t)f * max_rows + rows[f]) * 3;
+      r[0] = coef; r[1] = x; r[2] = cost;
+    }
+    rows[f]++;
+  };
+  {  // baseline: GetCost(profile, &CostFunc, 0, coefs[0].vdef, ...) (codec.cpp:386)
+    std::vector<Chain> chains(nframes);
+    for (int f = 0; f < nframes; f++) { chains[f].frame = f; memcpy(chains[f].coefs, cur[f].data(), 8 * pd.ncoef); }
+    if (eval_chains(c, pd, fr, chains, memo)) return 1;
+    std::vector<double> costs;
+    if (cost_round(c, pd, fr, chains, 1, d_state, costs)) return 1;
+    for (int f = 0; f < nframes; f++) { best_cost[f] = costs[f]; add_row(f, -1, cur[f][0], costs[f]); }
+  }
+  for (int i = 0; i < ncoef_loop; i++) {
+    const int nc = (int)grid[i].size();
+    if (!nc) continue;
+    std::vector<Chain> chains((size_t)nframes * nc);
+    for (int f = 0; f < nframes; f++)
+      for (int k = 0; k < nc; k++) {
+        Chain &ch = chains[(size_t)f * nc + k];
+        ch.frame = f;
+        memcpy(ch.coefs, cur[f].data(), 8 * pd.ncoef);
+        ch.coefs[i] = grid[i][k];
+      }
+    if (eval_chains(c, pd, fr, chains, memo)) return 1;
+    std::vector<double> costs;
+    if (cost_round(c, pd, fr, chains, nc, d_state, costs)) return 1;
+    for (int f = 0; f < nframes; f++) {
+      double best_x = cur[f][i];
+      for (int k = 0; k < nc; k++) {
+        const double cost = costs[(size_t)f * nc + k];
+        add_row(f, i, grid[i][k], cost);
+        if (cost < best_cost[f]) { best_x = grid[i][k]; best_cost[f] = cost; }  // strict <: earliest wins ties (codec.cpp:399)
+      }
+      cur[f][i] = best_x;  // later coefficients see earlier winners (codec.cpp:406)
+    }
+  }
+  for (int f = 0; f < nframes; f++) {
+    memcpy(best + (size_t)f * pd.ncoef, cur[f].data(), 8 * pd.ncoef);
+    if (rows_out) rows_out[f] = rows[f];
+  }
+  return end_timing(c);
+}
+
+// ------------------------------------------------------------------------------------------ cost on caller residuals
+extern "C" int sacopt_cost_golomb(sacopt_ctx *c, const int32_t *buf, int n, double *state_inout, double *cost) {
+  if (!c) return 1;
+  if (begin_call(c)) return 1;
+  if (n < 0 || !cost || (n && !buf)) { c->err = "bad arguments"; return 1; }
+  if (n == 0) { *cost = 0.; return 0; }  // codec.cpp:335: empty buffer -> 0, state untouched
+  if (arena_reserve(c, (size_t)n * 4 + (1 << 16))) return 1;
+  HIPCK(c, hipEventRecord(c->ev0, c->st));
+  const int32_t *d = buf;
+  if (!is_device_ptr(buf)) {
+    int32_t *p = arena_alloc<int32_t>(c, n);
+    HIPCK(c, hipMemcpyAsync(p, buf, (size_t)n * 4, hipMemcpyHostToDevice, c->st));
+    d = p;
+  }
+  // single-buffer mode of k_cost (nbuf < 0): cost = Calc(buf), state carried
+  std::vector<const int32_t *> bufs = {d, d};
+  const int32_t **d_bufs;
+  if (upload(c, bufs, &d_bufs)) return 1;
+  std::vector<double> stv = {state_inout ? *state_inout : 0.};
+  double *d_state;
+  if (upload(c, stv, &d_state)) return 1;
+  double *d_cost = arena_alloc<double>(c, 2);
+  CostJob j;
+  j.bufs = d_bufs; j.costs = d_cost; j.state = d_state; j.n = n; j.nbuf = -1;  // nbuf < 0: single-buffer mode
+  std::vector<CostJob> jobs = {j};
+  CostJob *dj;
+  if (upload(c, jobs, &dj)) return 1;
+  if (sacopt_launch_cost(dj, 1, c->d_pow2, c->st)) { c->err = "k_cost launch failed"; return 1; }
+  HIPCK(c, hipMemcpyAsync(cost, d_cost, 8, hipMemcpyDeviceToHost, c->st));
+  if (state_inout) HIPCK(c, hipMemcpyAsync(state_inout, d_state, 8, hipMemcpyDeviceToHost, c->st));
+  return end_timing(c);
+}
+
+extern "C" int sacopt_cost_meanrms(sacopt_ctx *c, const int32_t *buf, int n, double *cost) {
+  if (!c) return 1;
+  if (begin_call(c)) return 1;
+  if (n < 0 || !cost || (n && !buf)) { c->err = "bad arguments"; return 1; }
+  if (n == 0) { *cost = 0.; return 0; }
+  if (arena_reserve(c, (size_t)n * 4 + (1 << 16))) return 1;
+  HIPCK(c, hipEventRecord(c->ev0, c->st));
+  const int32_t *d = buf;
+  if (!is_device_ptr(buf)) {
+    int32_t *p = arena_alloc<int32_t>(c, n);
+    HIPCK(c, hipMemcpyAsync(p, buf, (size_t)n * 4, hipMemcpyHostToDevice, c->st));
+    d = p;
+  }
+  double *d_cost = arena_alloc<double>(c, 1);
+  if (sacopt_launch_meanrms(d, n, d_cost, c->st)) { c->err = "k_meanrms launch failed"; return 1; }
+  HIPCK(c, hipMemcpyAsync(cost, d_cost, 8, hipMemcpyDeviceToHost, c->st));
+  return end_timing(c);
+}
+
+// ------------------------------------------------------------------------------------------ stage-level entry points
+template <class T>
+static int to_dev(sacopt_ctx *c, const T *src, size_t count, const T **out) {
+  if (is_device_ptr(src)) { *out = src; return 0; }
+  T *p = arena_alloc<T>(c, count);
+  if (!p) { c->err = "device arena exhausted"; return 1; }
+  HIPCK(c, hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, c->st));
+  *out = p;
+  return 0;
+}
+
+extern "C" int sacopt_lms_pair(sacopt_ctx *c, int S, int D, double mu1, double mu2, const double *x0, const double *x1, int n,
+                               double *p0, double *p1) {
+  if (!c) return 1;
+  if (begin_call(c)) return 1;
+  if (n < 0 || (n && (!x0 || !x1 || !p0 || !p1))) { c->err = "bad arguments"; return 1; }
+  if (!n) return 0;
+  if (arena_reserve(c, (size_t)n * 8 * 4 + (1 << 16))) return 1;
+  HIPCK(c, hipEventRecord(c->ev0, c->st));
+  LmsJob j;
+  memset(&j, 0, sizeof(j));
+  if (to_dev(c, x0, n, &j.x[0]) || to_dev(c, x1, n, &j.x[1])) return 1;
+  j.p[0] = arena_alloc<double>(c, n);
+  j.p[1] = arena_alloc<double>(c, n);
+  j.mu1 = mu1; j.mu2 = mu2; j.n = n;
+  std::vector<LmsJob> jobs = {j};
+  LmsJob *dj;
+  if (upload(c, jobs, &dj)) return 1;
+  hipEvent_t a, b;
+  HIPCK(c, hipEventCreate(&a));
+  HIPCK(c, hipEventCreate(&b));
+  HIPCK(c, hipEventRecord(a, c->st));
+  if (sacopt_launch_lms(S, D, dj, 1, c->d_tab, c->bits, c->st)) { c->err = "unsupported (S,D) or launch failure"; return 1; }
+  HIPCK(c, hipEventRecord(b, c->st));
+  c->lms_ev.push_back({a, b});
+  if (copy_out(c, p0, j.p[0], (size_t)n * 8) || copy_out(c, p1, j.p[1], (size_t)n * 8)) return 1;
+  return end_timing(c);
+}
+
+extern "C" int sacopt_lpc3_pair(sacopt_ctx *c, double alpha, const int32_t *s0, const int32_t *s1, int n, double *p0, double *p1) {
+  if (!c) return 1;
+  if (begin_call(c)) return 1;
+  if (n < 0 || (n && (!s0 || !s1 || !p0 || !p1))) { c->err = "bad arguments"; return 1; }
+  if (!n) return 0;
+  if (arena_reserve(c, (size_t)n * 8 * 6 + (1 << 16))) return 1;
+  HIPCK(c, hipEventRecord(c->ev0, c->st));
+  LpcJob j;
+  memset(&j, 0, sizeof(j));
+  if (to_dev(c, s0, n, &j.s[0]) || to_dev(c, s1, n, &j.s[1])) return 1;
+  for (int k = 0; k < 2; k++) { j.p[k] = arena_alloc<double>(c, n); j.x1[k] = arena_alloc<double>(c, n); }
+  j.alpha = alpha; j.n = n;
+  std::vector<LpcJob> jobs = {j};
+  LpcJob *dj;
+  if (upload(c, jobs, &dj)) return 1;
+  if (sacopt_launch_lpc3(dj, 1, c->st)) { c->err = "k_lpc3 launch failed"; return 1; }
+  if (copy_out(c, p0, j.p[0], (size_t)n * 8) || copy_out(c, p1, j.p[1], (size_t)n * 8)) return 1;
+  return end_timing(c);
+}
+
+extern "C" int sacopt_rls_run(sacopt_ctx *c, int nst, double alpha, const double *pv, const double *val, int len, double *p) {
+  if (!c) return 1;
+  if (begin_call(c)) return 1;
+  if (len < 0 || (len && (!pv || !val || !p))) { c->err = "bad arguments"; return 1; }
+  if (nst != 3 && nst != 4) { c->err = "RLS order must be 3 or 4"; return 1; }
+  if (!len) return 0;
+  if (arena_reserve(c, (size_t)len * 8 * (nst + 3) + (1 << 16))) return 1;
+  HIPCK(c, hipEventRecord(c->ev0, c->st));
+  const double *dpv, *dval;
+  if (to_dev(c, pv, (size_t)len * nst, &dpv) || to_dev(c, val, len, &dval)) return 1;
+  double *dp = arena_alloc<double>(c, len);
+  if (sacopt_launch_rls(nst, dpv, dval, len, alpha, dp, c->st)) { c->err = "k_rls launch failed"; return 1; }
+  if (copy_out(c, p, dp, (size_t)len * 8)) return 1;
+  return end_timing(c);
+}

@@ -1,0 +1,229 @@
+"""ctypes binding of libsacopt.so (include/sacopt.h) -- plumbing for tests and bench.py.
+
+The library is the product; this module only marshals numpy arrays / raw device pointers into
+the C ABI. There is no fallback: if libsacopt.so is missing or no gfx950 GPU is usable, loading
+or `Context()` raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsacopt.so")
+
+PROFILE_FAST, PROFILE_NORMAL, PROFILE_HIGH = 0, 1, 2
+NCOEF = {0: 1, 1: 6, 2: 8}
+
+
+class Frame(C.Structure):
+    _fields_ = [("s0", C.c_void_p), ("s1", C.c_void_p), ("numsamples", C.c_int32)]
+
+
+class Residuals(C.Structure):
+    _fields_ = [("err0", C.c_void_p), ("err1", C.c_void_p), ("s2u0", C.c_void_p), ("s2u1", C.c_void_p),
+                ("map0", C.c_void_p), ("map1", C.c_void_p), ("maxbpn", C.c_int32 * 4)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} not built: run `make -C sac_amd/csrc` (or __graft_entry__.build())")
+        L = C.CDLL(LIB_PATH)
+        L.sacopt_last_error.restype = C.c_char_p
+        L.sacopt_last_error.argtypes = [C.c_void_p]
+        L.sacopt_create.argtypes = [C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+        L.sacopt_destroy.argtypes = [C.c_void_p]
+        L.sacopt_destroy.restype = None
+        L.sacopt_probe_rsqrt.argtypes = [C.c_void_p, C.c_int]
+        L.sacopt_base_profile.argtypes = [C.c_int, C.c_void_p]
+        L.sacopt_predict_stereo_frames.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                   C.c_void_p, C.c_void_p]
+        L.sacopt_get_costs.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                       C.c_void_p, C.c_void_p, C.c_void_p]
+        L.sacopt_optimize_frames.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                             C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.sacopt_cost_golomb.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.sacopt_cost_meanrms.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.sacopt_lms_pair.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p,
+                                      C.c_int, C.c_void_p, C.c_void_p]
+        L.sacopt_lpc3_pair.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.sacopt_rls_run.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.sacopt_last_timing.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+EXPORTS = ["sacopt_create", "sacopt_destroy", "sacopt_last_error", "sacopt_probe_rsqrt", "sacopt_base_profile",
+           "sacopt_predict_stereo_frames", "sacopt_get_costs", "sacopt_optimize_frames", "sacopt_cost_golomb",
+           "sacopt_cost_meanrms", "sacopt_lms_pair", "sacopt_lpc3_pair", "sacopt_rls_run", "sacopt_last_timing"]
+
+
+def _p(a):
+    """numpy array -> host pointer; int -> raw (device) pointer; None -> NULL."""
+    if a is None:
+        return None
+    if isinstance(a, (int, np.integer)):
+        return C.c_void_p(int(a))
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def probe_rsqrt(cap=4096):
+    tab = np.zeros(cap, np.float32)
+    bits = lib().sacopt_probe_rsqrt(_p(tab), cap)
+    if bits < 0:
+        raise RuntimeError("host rsqrtss does not fit the table model")
+    return tab[:2 << bits].copy(), bits
+
+
+def base_profile(profile):
+    out = np.zeros(24)
+    n = lib().sacopt_base_profile(profile, _p(out))
+    return out[:3 * n].reshape(n, 3).copy()
+
+
+class SacoptError(RuntimeError):
+    pass
+
+
+class Context:
+    """One per GPU. rsqrt_tab=None probes the CPU this process runs on."""
+
+    def __init__(self, device=0, rsqrt_tab=None, rsqrt_bits=0):
+        self._h = C.c_void_p()
+        tab = None if rsqrt_tab is None else np.ascontiguousarray(rsqrt_tab, dtype=np.float32)
+        rc = lib().sacopt_create(device, _p(tab), rsqrt_bits, C.byref(self._h))
+        if rc:
+            raise SacoptError(lib().sacopt_last_error(None).decode())
+
+    def close(self):
+        if self._h:
+            lib().sacopt_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc:
+            raise SacoptError(lib().sacopt_last_error(self._h).decode())
+
+    @staticmethod
+    def _frames(frames):
+        """frames: list of (s0, s1[, numsamples]); s* numpy int32 arrays or raw device pointers."""
+        arr = (Frame * max(len(frames), 1))()
+        keep = []
+        for i, fr in enumerate(frames):
+            s0, s1 = fr[0], fr[1]
+            if isinstance(s0, np.ndarray):
+                s0 = np.ascontiguousarray(s0, dtype=np.int32)
+                s1 = np.ascontiguousarray(s1, dtype=np.int32)
+                n = len(s0) if len(fr) < 3 else fr[2]
+                keep += [s0, s1]
+                arr[i].s0, arr[i].s1 = s0.ctypes.data, s1.ctypes.data
+            else:
+                n = fr[2]
+                arr[i].s0, arr[i].s1 = int(s0), int(s1)
+            arr[i].numsamples = n
+        return arr, keep
+
+    def predict(self, profile, frames, frm=None, n=None, coefs=None, device_out=None):
+        """Returns list of dicts (e0,e1,u0,u1,maxbpn) as numpy arrays; with device_out (list of dicts of
+        raw device pointers) the residuals are left on the device."""
+        nf = len(frames)
+        arr, keep = self._frames(frames)
+        frm_a = None if frm is None else np.ascontiguousarray(frm, dtype=np.int32)
+        n_a = None if n is None else np.ascontiguousarray(n, dtype=np.int32)
+        cf = None if coefs is None else np.ascontiguousarray(coefs, dtype=np.float64)
+        res = (Residuals * max(nf, 1))()
+        outs = []
+        for i in range(nf):
+            ni = int(n_a[i]) if n_a is not None else arr[i].numsamples - (int(frm_a[i]) if frm_a is not None else 0)
+            if device_out is None:
+                d = {k: np.zeros(max(ni, 0), np.int32) for k in ("e0", "e1", "u0", "u1")}
+                res[i].err0, res[i].err1 = d["e0"].ctypes.data, d["e1"].ctypes.data
+                res[i].s2u0, res[i].s2u1 = d["u0"].ctypes.data, d["u1"].ctypes.data
+            else:
+                d = {}
+                res[i].err0, res[i].err1 = device_out[i].get("e0"), device_out[i].get("e1")
+                res[i].s2u0, res[i].s2u1 = device_out[i].get("u0"), device_out[i].get("u1")
+            outs.append(d)
+        self._ck(lib().sacopt_predict_stereo_frames(self._h, profile, nf, arr, _p(frm_a), _p(n_a), _p(cf), res))
+        for i in range(nf):
+            outs[i]["maxbpn"] = np.array(list(res[i].maxbpn), np.int32)
+        return outs
+
+    def get_costs(self, profile, frames, cand_coefs, frm=None, n=None, state=None):
+        """cand_coefs: [nframes, ncand, ncoef]. Returns (costs[nframes,ncand], state[nframes])."""
+        nf = len(frames)
+        arr, keep = self._frames(frames)
+        cc = np.ascontiguousarray(cand_coefs, dtype=np.float64)
+        ncand = cc.shape[1]
+        frm_a = None if frm is None else np.ascontiguousarray(frm, dtype=np.int32)
+        n_a = None if n is None else np.ascontiguousarray(n, dtype=np.int32)
+        costs = np.zeros((nf, ncand))
+        st = np.zeros(nf) if state is None else np.ascontiguousarray(state, dtype=np.float64).copy()
+        self._ck(lib().sacopt_get_costs(self._h, profile, nf, arr, _p(frm_a), _p(n_a), ncand, _p(cc), _p(costs), _p(st)))
+        return costs, st
+
+    def optimize(self, profile, frames, prof=None, ncoef_loop=None, max_rows=128):
+        """FrameCoder::Optimize for every frame. Returns (best[nframes,ncoef], trace list, rows)."""
+        nf = len(frames)
+        arr, keep = self._frames(frames)
+        nc = NCOEF[profile]
+        if ncoef_loop is None:
+            ncoef_loop = nc
+        pf = None if prof is None else np.ascontiguousarray(prof, dtype=np.float64)
+        best = np.zeros((nf, nc))
+        trace = np.zeros((nf, max_rows, 3))
+        rows = np.zeros(nf, np.int32)
+        self._ck(lib().sacopt_optimize_frames(self._h, profile, nf, arr, _p(pf), ncoef_loop, _p(best), _p(trace),
+                                              max_rows, _p(rows)))
+        return best, [trace[f, :min(rows[f], max_rows)].copy() for f in range(nf)], rows
+
+    def cost_golomb(self, buf, state=0.0):
+        st = np.array([state], np.float64)
+        cost = np.zeros(1)
+        if isinstance(buf, np.ndarray):
+            buf = np.ascontiguousarray(buf, dtype=np.int32)
+            n = len(buf)
+        else:
+            buf, n = buf
+        self._ck(lib().sacopt_cost_golomb(self._h, _p(buf), n, _p(st), _p(cost)))
+        return float(cost[0]), float(st[0])
+
+    def cost_meanrms(self, buf):
+        buf = np.ascontiguousarray(buf, dtype=np.int32)
+        cost = np.zeros(1)
+        self._ck(lib().sacopt_cost_meanrms(self._h, _p(buf), len(buf), _p(cost)))
+        return float(cost[0])
+
+    def lms_pair(self, S, D, mu1, mu2, x0, x1):
+        x0 = np.ascontiguousarray(x0, dtype=np.float64); x1 = np.ascontiguousarray(x1, dtype=np.float64)
+        p0 = np.zeros(len(x0)); p1 = np.zeros(len(x0))
+        self._ck(lib().sacopt_lms_pair(self._h, S, D, mu1, mu2, _p(x0), _p(x1), len(x0), _p(p0), _p(p1)))
+        return p0, p1
+
+    def lpc3_pair(self, alpha, s0, s1):
+        s0 = np.ascontiguousarray(s0, dtype=np.int32); s1 = np.ascontiguousarray(s1, dtype=np.int32)
+        p0 = np.zeros(len(s0)); p1 = np.zeros(len(s0))
+        self._ck(lib().sacopt_lpc3_pair(self._h, alpha, _p(s0), _p(s1), len(s0), _p(p0), _p(p1)))
+        return p0, p1
+
+    def rls_run(self, nst, alpha, pv, val):
+        pv = np.ascontiguousarray(pv, dtype=np.float64); val = np.ascontiguousarray(val, dtype=np.float64)
+        p = np.zeros(len(val))
+        self._ck(lib().sacopt_rls_run(self._h, nst, alpha, _p(pv), _p(val), len(val), _p(p)))
+        return p
+
+    def last_timing(self):
+        t = C.c_double(); l = C.c_double(); k = C.c_int()
+        lib().sacopt_last_timing(self._h, C.byref(t), C.byref(l), C.byref(k))
+        return dict(total_ms=t.value, lms_ms=l.value, lms_launches=k.value)

@@ -1,0 +1,135 @@
+"""GPU: libsacopt (HIP, through the C ABI) against the oracle and the golden fixtures.
+Bit-exact everywhere: int32 residuals, FP64 stage outputs / costs / selected parameters
+compared as raw bits. All runs use the FIXTURE's rsqrtss table (Intel), so they do not depend
+on the CPU of the GPU box."""
+import numpy as np
+import pytest
+
+from sac_amd import sacopt
+from sac_amd.synth import stereo_clip
+
+pytestmark = pytest.mark.gpu
+
+
+def same_bits(a, b):
+    a = np.ascontiguousarray(a); b = np.ascontiguousarray(b)
+    return a.shape == b.shape and a.tobytes() == b.tobytes()
+
+
+@pytest.fixture(scope="module")
+def ctx(rsqrt_table):
+    c = sacopt.Context(0, *rsqrt_table)
+    yield c
+    c.close()
+
+
+# ---------------------------------------------------------------- stage kernels vs golden
+@pytest.mark.parametrize("S,D,m1,m2", [(8, 4, 0.01, 0.01), (32, 16, 3e-3, 3e-3), (256, 128, 5e-4, 1e-4), (1280, 640, 1e-5, 5e-6)])
+def test_lms_pair_golden(ctx, golden, S, D, m1, m2):
+    p0, p1 = ctx.lms_pair(S, D, m1, m2, golden["lms_x0"], golden["lms_x1"])
+    assert same_bits(p0, golden[f"lms{S}_p0"]) and same_bits(p1, golden[f"lms{S}_p1"])
+
+
+def test_lpc3_pair_golden(ctx, golden):
+    p0, p1 = ctx.lpc3_pair(0.997, golden["pred_L"][:3000], golden["pred_R"][:3000])
+    assert same_bits(p0, golden["lpc3_p0"]) and same_bits(p1, golden["lpc3_p1"])
+
+
+def test_rls_golden(ctx, golden):
+    assert same_bits(ctx.rls_run(4, 0.998, golden["rls_pv"], golden["rls_val"]), golden["rls4_p"])
+    assert same_bits(ctx.rls_run(3, 0.998, np.ascontiguousarray(golden["rls_pv"][:, :3]), golden["rls_val"]), golden["rls3_p"])
+
+
+def test_cost_golden(ctx, golden):
+    e = golden["cost_e"]
+    c1, s1 = ctx.cost_golomb(e[:2500], 0.0)
+    c2, s2 = ctx.cost_golomb(e[2500:], s1)
+    assert same_bits(np.array([c1, s1, c2, s2, ctx.cost_meanrms(e)]), golden["cost_vals"])
+    assert ctx.cost_golomb(e[:0], 1.5) == (0.0, 1.5)
+
+
+# ---------------------------------------------------------------- PredictStereoFrame
+@pytest.mark.parametrize("prof", [0, 1, 2])
+def test_predict_golden(ctx, golden, prof):
+    L, R = golden["pred_L"], golden["pred_R"]
+    out = ctx.predict(prof, [(L, R), (L, R)], frm=[0, 1500], n=[4096, 2000])
+    for key, tag in (("e0", "e0"), ("e1", "e1"), ("u0", "u0"), ("u1", "u1")):
+        assert np.array_equal(out[0][key], golden[f"pred{prof}_{tag}"]), key
+        assert np.array_equal(out[1][key], golden[f"predw{prof}_{tag}"]), key
+    assert np.array_equal(out[0]["maxbpn"][:2], golden[f"pred{prof}_maxbpn"][:2])
+    assert np.array_equal(out[1]["maxbpn"][:2], golden[f"predw{prof}_maxbpn"][:2])
+
+
+def test_predict_custom_coefs_golden(ctx, golden):
+    out = ctx.predict(2, [(golden["pred_L"], golden["pred_R"])], frm=[0], n=[3000], coefs=golden["predc_coefs"][None, :])
+    assert np.array_equal(out[0]["e0"], golden["predc_e0"]) and np.array_equal(out[0]["e1"], golden["predc_e1"])
+
+
+@pytest.mark.parametrize("prof,seed,n", [(0, 31, 5000), (1, 32, 5000), (2, 33, 6000)])
+def test_predict_vs_oracle(ctx, oracle, prof, seed, n):
+    L, R = stereo_clip(seed, n)
+    ref = oracle.predict(prof, L, R)
+    out = ctx.predict(prof, [(L, R)])[0]
+    for k in ("e0", "e1", "u0", "u1"):
+        assert np.array_equal(out[k], ref[k]), k
+
+
+def test_predict_edge_cases(ctx, oracle):
+    # empty frame, 1-sample frame, ragged batch, silence, full-scale
+    L, R = stereo_clip(34, 700)
+    Z = np.zeros(300, np.int32)
+    rs = np.random.RandomState(5)
+    Lf = (np.sign(np.sin(np.arange(900) * 0.05)) * 30000 + rs.randint(-2000, 2000, 900)).astype(np.int32)
+    Rf = (-Lf // 2 + rs.randint(-500, 500, 900)).astype(np.int32)
+    frames = [(L[:0], R[:0]), (L[:1], R[:1]), (L, R), (Z, Z), (Lf, Rf)]
+    for prof in (0, 1, 2):
+        outs = ctx.predict(prof, frames)
+        for (a, b), o in zip(frames, outs):
+            ref = oracle.predict(prof, a, b) if len(a) else dict(e0=a, e1=b)
+            assert np.array_equal(o["e0"], ref["e0"]) and np.array_equal(o["e1"], ref["e1"]), prof
+
+
+# ---------------------------------------------------------------- GetCost / Optimize
+def test_get_costs_vs_oracle(ctx, oracle):
+    L, R = stereo_clip(35, 4000)
+    base = sacopt.base_profile(2)[:, 2]
+    cands = np.tile(base, (3, 1))
+    cands[1, 1] = 3e-5
+    cands[2, 7] = 0.9995
+    costs, st = ctx.get_costs(2, [(L, R)], cands[None], frm=[500], n=[3000], state=[2.5])
+    mean = 2.5
+    for k in range(3):
+        r = oracle.predict(2, L, R, frm=500, n=3000, coefs=cands[k])
+        c1, mean = oracle.cost_golomb(r["e0"], mean)
+        c2, mean = oracle.cost_golomb(r["e1"], mean)
+        assert same_bits(np.array([(c1 + c2) / 2.]), costs[0, k:k + 1]), k
+    assert same_bits(np.array([mean]), st)
+
+
+def test_optimize_golden(ctx, golden):
+    # FrameCoder::Optimize: identical selected parameters AND identical 84-row cost trace (bit-exact)
+    frames = [(golden["opt_L"], golden["opt_R"]), (golden["opt2_L"], golden["opt2_R"])]
+    best, traces, rows = ctx.optimize(2, frames)
+    assert list(rows) == [84, 84]
+    assert same_bits(best[0], golden["opt_best"]) and same_bits(traces[0], golden["opt_trace"])
+    assert same_bits(best[1], golden["opt2_best"]) and same_bits(traces[1], golden["opt2_trace"])
+
+
+def test_optimize_normal_profile_golden(ctx, golden):
+    best, traces, rows = ctx.optimize(1, [(golden["opt_L"], golden["opt_R"])], ncoef_loop=6)
+    assert same_bits(best[0], golden["optn_best"]) and same_bits(traces[0], golden["optn_trace"])
+
+
+def test_optimize_rejects_reference_ub(ctx, golden):
+    # the reference indexes coefs[0..7] for every profile (codec.cpp:389): UB for fast/normal -> error here
+    with pytest.raises(sacopt.SacoptError):
+        ctx.optimize(1, [(golden["opt_L"], golden["opt_R"])], ncoef_loop=8)
+
+
+def test_optimize_vs_oracle_ragged(ctx, oracle):
+    # a batch of frames of different lengths incl. one shorter than 8 samples (window n = 0)
+    frames = [stereo_clip(40 + i, n) for i, n in enumerate([4096, 3000, 5])]
+    best, traces, rows = ctx.optimize(2, frames)
+    for f, (L, R) in enumerate(frames):
+        ob, ot = oracle.optimize(2, L, R)
+        assert same_bits(best[f], ob) and same_bits(traces[f], ot), f
