@@ -53,7 +53,7 @@ def lib():
                                       C.c_int, C.c_void_p, C.c_void_p]
         L.sacopt_lpc3_pair.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.sacopt_rls_run.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
-        L.sacopt_last_timing.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.sacopt_last_timing.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -224,6 +224,6 @@ class Context:
         return p
 
     def last_timing(self):
-        t = C.c_double(); l = C.c_double(); k = C.c_int()
-        lib().sacopt_last_timing(self._h, C.byref(t), C.byref(l), C.byref(k))
-        return dict(total_ms=t.value, lms_ms=l.value, lms_launches=k.value)
+        t = C.c_double(); l = C.c_double(); k = C.c_int(); u = C.c_longlong()
+        lib().sacopt_last_timing(self._h, C.byref(t), C.byref(l), C.byref(k), C.byref(u))
+        return dict(total_ms=t.value, lms_ms=l.value, lms_launches=k.value, lms_units=u.value)
