@@ -6,7 +6,7 @@
 #include <stdint.h>
 
 #define LMS_CHUNK 512     // samples staged into the LDS history ring at a time
-#define RSQ_LDS_MAX 4096  // rsqrt table entries kept in LDS (bits <= 11)
+#define RSQ_LDS_MAX 8192  // rsqrt table entries kept in LDS (bits <= 12: Intel needs 10, AMD Zen 12)
 
 struct LmsJob {
   const double *x[2];  // stage inputs val[ch][k]      (n doubles each)

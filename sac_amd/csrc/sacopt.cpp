@@ -184,9 +184,9 @@ extern "C" int sacopt_create(int device, const float *rsqrt_tab, int rsqrt_bits,
   if (!rsqrt_tab) {
     tab.resize(RSQ_LDS_MAX);
     bits = sacopt_probe_rsqrt(tab.data(), RSQ_LDS_MAX);
-    if (bits < 0) { g_create_error = "host rsqrtss does not fit the parity x top-k-mantissa table model (k <= 11)"; return 1; }
+    if (bits < 0) { g_create_error = "host rsqrtss does not fit the parity x top-k-mantissa table model (k <= 12)"; return 1; }
   } else {
-    if (bits < 0 || (2 << bits) > RSQ_LDS_MAX) { g_create_error = "rsqrt_bits out of range (0..11)"; return 1; }
+    if (bits < 0 || (2 << bits) > RSQ_LDS_MAX) { g_create_error = "rsqrt_bits out of range (0..12)"; return 1; }
     tab.assign(rsqrt_tab, rsqrt_tab + (2 << bits));
   }
   sacopt_ctx *c = new sacopt_ctx;

@@ -72,7 +72,7 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
-def probe_rsqrt(cap=4096):
+def probe_rsqrt(cap=8192):
     tab = np.zeros(cap, np.float32)
     bits = lib().sacopt_probe_rsqrt(_p(tab), cap)
     if bits < 0:
