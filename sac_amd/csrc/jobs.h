@@ -22,9 +22,15 @@ struct LpcJob {
   double *x1[2];        // LPC3: val[ch][1] = v - p[0]
   int32_t *e[2];        // LPC2 (fast profile): error[ch]
   int32_t *u[2];        // LPC2: s2u_error[ch]
-  int32_t *umax;        // LPC2: [2] max s2u
+  int32_t *umax;        // LPC2: [2] max s2u (must be zeroed before the launch)
   double alpha;
-  int32_t n, pad;
+  int32_t n, nsnap;     // nsnap = n / k  (k = 8 for LPC3, 32 for LPC2)
+  // scratch, per channel (released after the stage has run)
+  double *snap[2];      // [nsnap][324] covariance (packed lower triangle) + b after every k-th Update
+  double *sol[2];       // [nsnap][300] all-orders solutions (LPC2: [nsnap][24])
+  int32_t *fail[2];     // [nsnap] 1 = "matrix indefinit", previous solution stays in force
+  double *ss[2];        // [n][24] all-orders predictions   (LPC3)
+  double *serr[2];      // [n][24] BlendErr running errors  (LPC3)
 };
 
 struct MixJob {

@@ -6,7 +6,7 @@
 // Decomposition: the cascade of src/profile.cpp:113-186 is feed-forward between
 // stages (no stage reads a later stage's state), so every stage is its own time-serial kernel
 // over a window, one workgroup per (frame, candidate) chain:
-//     k_lpc3  -> k_lms<1280,640> -> k_lms<256,128> -> k_lms<32,16> -> k_lms<8,4> -> k_mix -> k_cost
+//     LPC (k_cov,k_chol,k_ssum,k_serr,k_pm) -> k_lms<1280,640> -> k_lms<256,128> -> k_lms<32,16> -> k_lms<8,4> -> k_mix -> k_cost
 //
 // Exact serial sums: the reference's dot products are strict left-to-right FP64 chains
 // (src/pred/nlms.h:110-111). v_mfma_f64_4x4x4 with B == 1.0 computes, per output row,
@@ -42,6 +42,44 @@ __device__ __forceinline__ double bcast(double v, int srclane) {
   return __hiloint2double(hi, lo);
 }
 
+
+// Exact serial sum of T4*4 LDS-resident products on the matrix pipe, hand-scheduled: the compiler
+// (ROCm 7.2) sinks LDS reads next to their use and drains lgkmcnt(0) per group, which doubled the
+// per-MFMA time (48 vs 23 cycles). Here the 8 operands of the next group are always in flight
+// under the 8 dependent MFMAs of the current one. `addr` = LDS byte address of this lane's first
+// operand; consecutive steps are 32 bytes apart. ITER = T4/16. Reads past the end return
+// unused data (still inside the workgroup's LDS allocation: the ring follows the products).
+#define MF(areg) "v_mfma_f64_4x4x4_4b_f64 %0, " areg ", %2, %0\n s_nop 3\n"
+template <int ITER>
+__device__ __forceinline__ double mfma_chain_lds(uint32_t addr) {
+  double acc = 0.;
+  double one = 1.0;
+  double a0, a1, a2, a3, a4, a5, a6, a7, b0, b1, b2, b3, b4, b5, b6, b7;
+  uint32_t cnt;
+  asm volatile(
+      "ds_read_b64 %3, %1\n ds_read_b64 %4, %1 offset:32\n ds_read_b64 %5, %1 offset:64\n ds_read_b64 %6, %1 offset:96\n"
+      "ds_read_b64 %7, %1 offset:128\n ds_read_b64 %8, %1 offset:160\n ds_read_b64 %9, %1 offset:192\n ds_read_b64 %10, %1 offset:224\n"
+      "s_mov_b32 %19, %20\n"
+      "1:\n"
+      "ds_read_b64 %11, %1 offset:256\n ds_read_b64 %12, %1 offset:288\n ds_read_b64 %13, %1 offset:320\n ds_read_b64 %14, %1 offset:352\n"
+      "ds_read_b64 %15, %1 offset:384\n ds_read_b64 %16, %1 offset:416\n ds_read_b64 %17, %1 offset:448\n ds_read_b64 %18, %1 offset:480\n"
+      "s_waitcnt lgkmcnt(8)\n s_nop 1\n"
+      MF("%3") MF("%4") MF("%5") MF("%6") MF("%7") MF("%8") MF("%9") MF("%10")
+      "v_add_u32 %1, 512, %1\n"
+      "ds_read_b64 %3, %1\n ds_read_b64 %4, %1 offset:32\n ds_read_b64 %5, %1 offset:64\n ds_read_b64 %6, %1 offset:96\n"
+      "ds_read_b64 %7, %1 offset:128\n ds_read_b64 %8, %1 offset:160\n ds_read_b64 %9, %1 offset:192\n ds_read_b64 %10, %1 offset:224\n"
+      "s_waitcnt lgkmcnt(8)\n s_nop 1\n"
+      MF("%11") MF("%12") MF("%13") MF("%14") MF("%15") MF("%16") MF("%17") MF("%18")
+      "s_sub_u32 %19, %19, 1\n s_cmp_lg_u32 %19, 0\n s_cbranch_scc1 1b\n"
+      "s_waitcnt lgkmcnt(0)\n s_nop 7\n"
+      : "+v"(acc), "+v"(addr), "+v"(one), "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(a4), "=&v"(a5), "=&v"(a6),
+        "=&v"(a7), "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3), "=&v"(b4), "=&v"(b5), "=&v"(b6), "=&v"(b7), "=&s"(cnt)
+      : "n"(ITER)
+      : "memory", "scc");
+  return acc;
+}
+#undef MF
+
 // ------------------------------------------------------------------------------------------
 // LMSADA2 stereo pair (src/pred/nlms.h:96-139), driven as StereoHigh/StereoNormal drive it
 // (src/profile.cpp:126-148,176-186):
@@ -53,18 +91,20 @@ __device__ __forceinline__ double bcast(double v, int srclane) {
 template <int S, int D, int NT, int R, int RL>
 __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, const float *__restrict__ gtab,
                                             int bits) {
-  constexpr int T = S + D, T4 = T / 4, PSTR = T4 + 1, M = RL - 1, CH = LMS_CHUNK;
+  constexpr int T = S + D, T4 = T / 4, M = RL - 1, CH = LMS_CHUNK;
   static_assert(T % 4 == 0, "tap count must be a multiple of 4");
   static_assert(RL >= CH + (S > D ? S : D) + 1, "ring too short");
   static_assert(NT * R >= 2 * T, "not enough tap slots");
-  constexpr int U = (T4 % 8 == 0) ? 8 : (T4 % 4 == 0) ? 4 : (T4 % 3 == 0) ? 3 : 1;
+  static_assert(T4 % 16 == 0 || T4 <= 16, "unsupported tap count");
+  __shared__ double prods[2][T];
   __shared__ double ring[2][RL];
-  __shared__ double prods[2][4][PSTR];
   __shared__ double predv[2];
   __shared__ float tab[RSQ_LDS_MAX];
 
   const LmsJob job = jobs[blockIdx.x];
   const int tid = threadIdx.x, n = job.n;
+  const int dbg = bits >> 8;  // DEBUG ablation flags
+  bits &= 0xff;
   for (int i = tid; i < (2 << bits); i += NT) tab[i] = gtab[i];
   for (int i = tid; i < 2 * RL; i += NT) (&ring[0][0])[i] = 0.;
   __syncthreads();
@@ -84,14 +124,15 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
     else { const int j = i - S; src = 1 - c; lag = (c == 0 ? 1 : 0) + j; mu[r] = job.mu2; }
     hsel[r] = src;
     hoff[r] = (-lag) & M;
-    paddr[r] = (c * 4 + (i & 3)) * PSTR + (i >> 2);
+    paddr[r] = c * T + i;
     w[r] = 0.; eg[r] = 0.;
     if (!valid[r]) { hsel[r] = 0; hoff[r] = 0; paddr[r] = 0; }
   }
   const int lane = tid & 63, wave = tid >> 6;
   const int mk = lane >> 4, mc = lane & 15;
-  const bool mact = mc < 2;
-  const double *mp = &prods[mact ? mc : 0][mk][0];
+  // MFMA operand map: lane (k = lane>>4, chain = lane&15) feeds term 4s+k of its chain at step s.
+  // Chains 0/1 are the two channels; chains 2..15 just repeat them (harmless, keeps loads unconditional).
+  const double *mp = &prods[mc & 1][mk];
 
   for (int t = 0; t < n; t++) {
     if ((t & (CH - 1)) == 0) {
@@ -107,19 +148,21 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
 #pragma unroll
     for (int r = 0; r < R; r++) {
       h[r] = ring[hsel[r]][(t + hoff[r]) & M];
-      if (valid[r]) (&prods[0][0][0])[paddr[r]] = w[r] * h[r];
+      if (valid[r] && !(dbg & 4)) (&prods[0][0])[paddr[r]] = w[r] * h[r];
     }
     __syncthreads();
     // ---- pred = 0.; for i: pred += w[i]*hist[i]  -- strict order, on the matrix pipe
     if (wave == 0) {
       double acc = 0.;
-#pragma unroll 1
-      for (int s0 = 0; s0 < T4; s0 += U) {
-        double a[U];
+      if (dbg & 1) acc = mp[t & 7]; else
+      if constexpr (T4 % 16 == 0) {
+        acc = mfma_chain_lds<T4 / 16>((uint32_t)(uintptr_t)mp);
+      } else {
+        double a[T4];
 #pragma unroll
-        for (int u = 0; u < U; u++) a[u] = mact ? mp[s0 + u] : 0.;
+        for (int u = 0; u < T4; u++) a[u] = mp[4 * u];
 #pragma unroll
-        for (int u = 0; u < U; u++) acc = __builtin_amdgcn_mfma_f64_4x4x4f64(a[u], 1.0, acc, 0, 0, 0);
+        for (int u = 0; u < T4; u++) acc = __builtin_amdgcn_mfma_f64_4x4x4f64(a[u], 1.0, acc, 0, 0, 0);
       }
       // chain c = 4*blk + i lives in D lanes 16*i + 4*blk + j: chain 0 -> lane 0, chain 1 -> lane 16
       if (lane == 0 || lane == 16) {
@@ -137,7 +180,7 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
     const double e1 = ring[1][t & M] - predv[1];
 #pragma unroll
     for (int r = 0; r < R; r++) {
-      if (valid[r]) {
+      if (valid[r] && !(dbg & 2)) {
         const double err = cs[r] ? e1 : e0;
         const double grad = err * h[r];
         eg[r] = 0.95 * eg[r] + (1.0 - 0.95) * (grad * grad);
@@ -149,180 +192,260 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
 
 // ------------------------------------------------------------------------------------------
 // LPC3(alpha, S=16, D=8, k=8, regp=500) (src/pred/lpc.h:172-228) incl. AutoCov (math/cov.h),
-// Cholesky all-orders solve (math/cholesky.cpp:16-77) and BlendErr (pred/blend.h:7-53).
-// The stage only ever sees input samples (no feedback from later stages), so both channels
-// run independently: one wave per (chain, channel); lane o owns order o / matrix row o.
-//   ch0: Predict(v1(t-1)) ; ch1: Predict(v0(t))       (profile.cpp:128, :150-158)
+// Cholesky all-orders solve (math/cholesky.cpp:16-77) and BlendErr (pred/blend.h:7-53);
+// LPC2(alpha,16,8,k=32,regp=0) (lpc.h:254-293) for the fast profile.
+//
+// The OLS stage only ever sees input samples (no feedback from any prediction), and inside it
+// the only true time recurrences are elementwise:  c[j][i] <- alpha*c[j][i] + h_i*h_j  (cov.h:25),
+// b[i] (cov.h:37) and BlendErr's serr[o] (blend.h:34). Everything else -- the Cholesky
+// factorisation + all-orders solve every k samples, the all-orders dot products, the weight
+// normalisation and the blended prediction -- depends only on those values at one time instant,
+// so it is computed in parallel over time, each scalar in the reference's operation order:
+//   k_cov   serial in t, one lane per matrix element       -> covariance snapshots every k samples
+//   k_chol  one wave per snapshot                           -> sol (all orders) per snapshot
+//   k_ssum  one thread per (t, order)                       -> ssum[t][o]        (lpc.h:195-199)
+//   k_serr  serial in t, one lane per order                 -> serr[t][o]        (blend.h:32-35)
+//   k_pm    one thread per t                                -> p[0](t), val[ch][1](t)
+//   ch0: Predict(v1(t-1)) ; ch1: Predict(v0(t))            (profile.cpp:128, :150-158)
 // ------------------------------------------------------------------------------------------
 #define LPC_N 24
 #define LPC_S 16
-#define LPC_RL 256
-#define LPC_CH 128
+#define LPC_TRI (LPC_N * (LPC_N + 1) / 2) /* 300 */
+#define LPC_SNAP (LPC_TRI + LPC_N)        /* 324: packed lower triangle + b */
+#define LPC_RL 1024
+#define LPC_CH 512
 __device__ __forceinline__ int32_t s2u(int32_t v) { return v < 0 ? 2 * (-v) : (v > 0 ? 2 * v - 1 : 0); }
 
-// FAST == false: LPC3 (k=8, regp=500, all orders + BlendErr) writing p[0] and val[ch][1].
-// FAST == true : LPC2 (src/pred/lpc.h:254-293; k=32, regp=0, full order only) as StereoFast
-//                uses it (src/profile.cpp:22-32), writing the residual directly.
-template <bool FAST>
-__global__ __launch_bounds__(64) void k_lpc(const LpcJob *__restrict__ jobs) {
+// hist[i] at time t for channel ch (cov.h:44-47 shifts expressed as indices into the inputs)
+__device__ __forceinline__ double lpc_hist(const int32_t *own, const int32_t *oth, int lagb, int i, int t) {
+  const int idx = (i < LPC_S) ? (t - 1 - i) : (t - lagb - (i - LPC_S));
+  const int32_t *src = (i < LPC_S) ? own : oth;
+  return idx >= 0 ? (double)src[idx] : 0.;
+}
+
+// AutoCov::UpdateCov/UpdateB (cov.h:19-43), snapshot after every KS-th Update (lpc.h:213-219)
+template <int KS>
+__global__ __launch_bounds__(384) void k_cov(const LpcJob *__restrict__ jobs) {
   constexpr int N = LPC_N, S = LPC_S, RL = LPC_RL, M = RL - 1, CH = LPC_CH;
-  constexpr int KSOLVE = FAST ? 32 : 8;
-  constexpr double REGP = FAST ? 0. : 500.;
   __shared__ double ring[2][RL];
-  __shared__ double cm[N + 1][N];
-  const LpcJob job = jobs[blockIdx.x];
+  const LpcJob &job = jobs[blockIdx.x];
   const int ch = blockIdx.y, oc = 1 - ch, lagb = (ch == 0) ? 1 : 0;
-  const int lane = threadIdx.x, n = job.n;
+  const int tid = threadIdx.x, n = job.n;
   const double alpha = job.alpha;
   const int32_t *s0 = job.s[0], *s1 = job.s[1];
-  double *pout = ch ? job.p[1] : job.p[0], *xout = ch ? job.x1[1] : job.x1[0];
-  int32_t *eout = ch ? job.e[1] : job.e[0], *uout = ch ? job.u[1] : job.u[0];
-  for (int i = lane; i < 2 * RL; i += 64) (&ring[0][0])[i] = 0.;
-  for (int i = lane; i < (N + 1) * N; i += 64) (&cm[0][0])[i] = 0.;
-
-  // covariance slots: element e = lane + 64 r of the packed lower triangle -> (j, i<=j)
-  double cv[5];
-  int cj[5], ci[5], ai[5], aj[5];  // (ring << 16) | offset of hist[i], hist[j] relative to t
-  bool cval[5];
-  auto haddr = [&](int i) -> int {
-    if (i < S) return ((-(1 + i)) & M) | (ch << 16);
-    return ((-(lagb + (i - S))) & M) | (oc << 16);
+  double *snap = ch ? job.snap[1] : job.snap[0];
+  for (int i = tid; i < 2 * RL; i += 384) (&ring[0][0])[i] = 0.;
+  // element e: e < 300 -> c[j][i] (packed j(j+1)/2+i); 300..323 -> b[e-300]
+  const int e = tid;
+  const bool isc = e < LPC_TRI, isb = !isc && e < LPC_SNAP;
+  int j = 0, i = 0;
+  if (isc) { while ((j + 1) * (j + 2) / 2 <= e) j++; i = e - j * (j + 1) / 2; }
+  else if (isb) i = e - LPC_TRI;
+  auto haddr = [&](int q) -> int {
+    if (q < S) return ((-(1 + q)) & M) | (ch << 16);
+    return ((-(lagb + (q - S))) & M) | (oc << 16);
   };
-#pragma unroll
-  for (int r = 0; r < 5; r++) {
-    const int e = lane + 64 * r;
-    cval[r] = e < N * (N + 1) / 2;
-    int j = 0;
-    while ((j + 1) * (j + 2) / 2 <= e) j++;
-    const int i = e - j * (j + 1) / 2;
-    cj[r] = cval[r] ? j : 0; ci[r] = cval[r] ? i : 0;
-    cv[r] = (cval[r] && i == j) ? 1.0 : 0.0;  // cov.h:17
-    ai[r] = haddr(ci[r]); aj[r] = haddr(cj[r]);
-  }
-  const int ab = haddr(lane < N ? lane : 0);
-  auto hist_at = [&](int a, int t) -> double { return ring[a >> 16][(t + (a & 0xffff)) & M]; };
-
-  double bv = 0., serr = 0., bw = 0.;
-  double sol[N];
-#pragma unroll
-  for (int i = 0; i < N; i++) sol[i] = 0.;
-  int nk = 0;
-  int32_t umax = 0;
-
+  const int ai = haddr(i), aj = haddr(j);
+  double cv = (isc && i == j) ? 1.0 : 0.0;  // cov.h:17
   for (int t = 0; t < n; t++) {
     if ((t & (CH - 1)) == 0) {
       __syncthreads();
-      for (int idx = lane; idx < 2 * CH; idx += 64) {
+      for (int idx = tid; idx < 2 * CH; idx += 384) {
         const int c = idx / CH, k = idx - c * CH, tau = t + k;
         const int32_t *ss = c ? s1 : s0;
         ring[c][tau & M] = (tau < n) ? (double)ss[tau] : 0.;
       }
       __syncthreads();
     }
-    const double v = ring[ch][t & M];
-    double ss = 0.;
-    if constexpr (!FAST) {
-      // ---- LPC3::Predict (lpc.h:186-201): all orders, then BlendErr::Predict (blend.h:13-29)
-#pragma unroll
-      for (int i = 0; i < N; i++) {
-        const double hi = (i < S) ? ring[ch][(t - 1 - i) & M] : ring[oc][(t - lagb - (i - S)) & M];
-        if (i <= lane) ss += sol[i] * hi;
-      }
-      const double q = bw * ss;
-      double pm = 0.;
-#pragma unroll
-      for (int i = 0; i < N; i++) pm += bcast(q, i);
-      if (lane == 0) {
-        pout[t] = pm;
-        xout[t] = v - pm;  // val[ch][1] = val[ch][0] - p[0] (profile.cpp:144)
-      }
-      // BlendErr::Update (blend.h:30-46); serr[n] is dead state and not kept
-      const double e = (v - ss);
-      serr = 0.98 * serr + (1. - 0.98) * (e * e);
-      const double tt = 10000. / (serr + 0.0001);
-      double wv = tt * tt;
-      double wsum = 0;
-#pragma unroll
-      for (int i = 0; i < N; i++) wsum += bcast(wv, i);
-      if (wsum > 0) wv /= wsum;
-      bw = (lane < N) ? wv : 0.;
-    } else {
-      // ---- LPC2::Predict (lpc.h:261-267); sol is wave-uniform
-#pragma unroll
-      for (int i = 0; i < N; i++) {
-        const double hi = (i < S) ? ring[ch][(t - 1 - i) & M] : ring[oc][(t - lagb - (i - S)) & M];
-        ss += sol[i] * hi;
-      }
-      if (lane == 0) {  // err = val - round(p) (profile.cpp:30-31)
-        const int32_t e = (int32_t)(v - round(ss));
-        const int32_t ue = s2u(e);
-        if (eout) eout[t] = e;
-        if (uout) uout[t] = ue;
-        umax = ue > umax ? ue : umax;
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < 5; r++)  // AutoCov::UpdateCov (cov.h:19-31)
-      if (cval[r]) cv[r] = alpha * cv[r] + (hist_at(ai[r], t) * hist_at(aj[r], t));
-    if (lane < N) bv = alpha * bv + (v * hist_at(ab, t));  // UpdateB (cov.h:32-43)
+    const double hi = ring[ai >> 16][(t + (ai & 0xffff)) & M];
+    const double hj = isc ? ring[aj >> 16][(t + (aj & 0xffff)) & M] : ring[ch][t & M];  // b: val*hist[i]
+    if (isc) cv = alpha * cv + (hi * hj);
+    else if (isb) cv = alpha * cv + (hj * hi);
+    if (((t + 1) % KS) == 0 && (isc || isb)) snap[(size_t)(t / KS) * LPC_SNAP + e] = cv;
+  }
+}
 
-    if (++nk >= KSOLVE) {
-      nk = 0;
-      // gather row `lane` of the covariance (row 24 = b) through LDS
+// Cholesky::Factor + Solve for one snapshot (cholesky.cpp:16-77). Lane r owns matrix row r;
+// lane 24 carries CalcY (:37-46) as an extra row. Each scalar's inner sum runs in the
+// reference's k order. FAST: full-order Solve(b,x) only, regp = 0; else all orders, regp = 500.
+template <bool FAST>
+__global__ __launch_bounds__(64) void k_chol(const LpcJob *__restrict__ jobs) {
+  constexpr int N = LPC_N;
+  constexpr double REGP = FAST ? 0. : 500.;
+  const LpcJob &job = jobs[blockIdx.y >> 1];
+  const int ch = blockIdx.y & 1, k = blockIdx.x, lane = threadIdx.x;
+  if (k >= job.nsnap) return;
+  const double *snap = (ch ? job.snap[1] : job.snap[0]) + (size_t)k * LPC_SNAP;
+  double *solo = (ch ? job.sol[1] : job.sol[0]) + (size_t)k * (FAST ? N : LPC_TRI);
+  int32_t *failo = (ch ? job.fail[1] : job.fail[0]) + k;
+  double m[N];
+  const int row = lane <= N ? lane : 0;
 #pragma unroll
-      for (int r = 0; r < 5; r++)
-        if (cval[r]) cm[cj[r]][ci[r]] = cv[r];
-      if (lane < N) cm[N][lane] = bv;
-      __syncthreads();
-      double m[N];
-      const int row = lane <= N ? lane : 0;
+  for (int q = 0; q < N; q++) {
+    double v = 0.;
+    if (row < N) { if (q <= row) v = snap[row * (row + 1) / 2 + q]; }
+    else v = snap[LPC_TRI + q];
+    if (q == lane) v += REGP;  // cholesky.cpp:20
+    m[q] = v;
+  }
+  bool fail = false;
 #pragma unroll
-      for (int k = 0; k < N; k++) {
-        m[k] = cm[row][k];
-        if (k == lane) m[k] += REGP;  // regp (cholesky.cpp:20)
-      }
-      // Cholesky::Factor (cholesky.cpp:16-35), column by column; lane 24 carries CalcY (:37-46)
-      bool fail = false;
+  for (int j = 0; j < N; j++) {
+    if (!fail) {
+      double sum = m[j];
 #pragma unroll
-      for (int j = 0; j < N; j++) {
-        if (!fail) {
-          double sum = m[j];
-#pragma unroll
-          for (int k = 0; k < j; k++) sum -= (m[k] * bcast(m[k], j));
-          const double dj = bcast(sum, j);
-          if (dj > 0.) {
-            const double diag = sqrt(dj);
-            m[j] = (lane == j) ? diag : sum / diag;
-          } else fail = true;  // "matrix indefinit": keep the previous solution (lpc.h:216-218)
-        }
-      }
-      if (!fail) {
-        if constexpr (!FAST) {  // Cholesky::Solve(b) for every leading order (cholesky.cpp:63-77)
-#pragma unroll
-          for (int i = N - 1; i >= 0; i--) {
-            double sum = bcast(m[i], N);
-#pragma unroll
-            for (int j = i + 1; j < N; j++) {
-              const double mji = bcast(m[i], j);
-              if (j <= lane) sum -= (mji * sol[j]);
-            }
-            const double d = bcast(m[i], i);
-            if (i <= lane) sol[i] = sum / d;
-          }
-        } else {  // Cholesky::Solve(b, x) (cholesky.cpp:48-60), computed uniformly by every lane
-#pragma unroll
-          for (int i = N - 1; i >= 0; i--) {
-            double sum = bcast(m[i], N);
-#pragma unroll
-            for (int j = i + 1; j < N; j++) sum -= (bcast(m[i], j) * sol[j]);
-            sol[i] = sum / bcast(m[i], i);
-          }
-        }
-      }
+      for (int q = 0; q < j; q++) sum -= (m[q] * bcast(m[q], j));
+      const double dj = bcast(sum, j);
+      if (dj > 0.) {
+        const double diag = sqrt(dj);
+        m[j] = (lane == j) ? diag : sum / diag;
+      } else fail = true;  // "matrix indefinit": the previous solution stays in force (lpc.h:216-218)
     }
   }
-  if constexpr (FAST)
-    if (lane == 0 && job.umax) job.umax[ch] = umax;
+  if (lane == 0) *failo = fail ? 1 : 0;
+  if (fail) return;
+  double sol[N];
+#pragma unroll
+  for (int i = 0; i < N; i++) sol[i] = 0.;
+  if constexpr (!FAST) {  // Solve(b) for every leading order (cholesky.cpp:63-77): lane o = order o
+#pragma unroll
+    for (int i = N - 1; i >= 0; i--) {
+      double sum = bcast(m[i], N);
+#pragma unroll
+      for (int j = i + 1; j < N; j++) {
+        const double mji = bcast(m[i], j);
+        if (j <= lane) sum -= (mji * sol[j]);
+      }
+      const double d = bcast(m[i], i);
+      if (i <= lane) sol[i] = sum / d;
+    }
+    if (lane < N) {
+#pragma unroll
+      for (int i = 0; i < N; i++)
+        if (i <= lane) solo[lane * (lane + 1) / 2 + i] = sol[i];
+    }
+  } else {  // Solve(b, x) (cholesky.cpp:48-60), uniform across lanes
+#pragma unroll
+    for (int i = N - 1; i >= 0; i--) {
+      double sum = bcast(m[i], N);
+#pragma unroll
+      for (int j = i + 1; j < N; j++) sum -= (bcast(m[i], j) * sol[j]);
+      sol[i] = sum / bcast(m[i], i);
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < N; i++) solo[i] = sol[i];
+    }
+  }
+}
+
+// index of the snapshot whose solution is in force when predicting sample t (-1: none yet)
+template <int KS>
+__device__ __forceinline__ int lpc_sol_index(const int32_t *fail, int t) {
+  int k = t / KS - 1;  // snapshot k is taken after Update(t = KS*(k+1)-1)
+  while (k >= 0 && fail[k]) k--;
+  return k;
+}
+
+// LPC3::Predict all-orders sums (lpc.h:195-199): thread per (t, order)
+__global__ __launch_bounds__(256) void k_ssum(const LpcJob *__restrict__ jobs) {
+  const LpcJob &job = jobs[blockIdx.y >> 1];
+  const int ch = blockIdx.y & 1, n = job.n;
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int t = (int)(gid / LPC_N), o = (int)(gid % LPC_N);
+  if (t >= n) return;
+  const int32_t *own = ch ? job.s[1] : job.s[0], *oth = ch ? job.s[0] : job.s[1];
+  const int lagb = (ch == 0) ? 1 : 0;
+  const int k = lpc_sol_index<8>(ch ? job.fail[1] : job.fail[0], t);
+  double sum = 0.;
+  if (k >= 0) {
+    const double *sol = (ch ? job.sol[1] : job.sol[0]) + (size_t)k * LPC_TRI + o * (o + 1) / 2;
+    for (int i = 0; i <= o; i++) sum += sol[i] * lpc_hist(own, oth, lagb, i, t);
+  }
+  (ch ? job.ss[1] : job.ss[0])[(size_t)t * LPC_N + o] = sum;
+}
+
+// BlendErr running squared errors (blend.h:32-35): serial in t, lane per order
+__global__ __launch_bounds__(64) void k_serr(const LpcJob *__restrict__ jobs) {
+  const LpcJob &job = jobs[blockIdx.x];
+  const int ch = blockIdx.y, lane = threadIdx.x, n = job.n;
+  if (lane >= LPC_N) return;
+  const int32_t *own = ch ? job.s[1] : job.s[0];
+  const double *ss = ch ? job.ss[1] : job.ss[0];
+  double *so = ch ? job.serr[1] : job.serr[0];
+  double serr = 0.;
+  int t = 0;
+  for (; t + 8 <= n; t += 8) {
+    double q[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const double e = ((double)own[t + u] - ss[(size_t)(t + u) * LPC_N + lane]);
+      q[u] = (1. - 0.98) * (e * e);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      serr = 0.98 * serr + q[u];
+      so[(size_t)(t + u) * LPC_N + lane] = serr;
+    }
+  }
+  for (; t < n; t++) {
+    const double e = ((double)own[t] - ss[(size_t)t * LPC_N + lane]);
+    serr = 0.98 * serr + (1. - 0.98) * (e * e);
+    so[(size_t)t * LPC_N + lane] = serr;
+  }
+}
+
+// BlendErr weights (blend.h:38-45) + blended prediction (blend.h:15-17): thread per t
+__global__ __launch_bounds__(256) void k_pm(const LpcJob *__restrict__ jobs) {
+  const LpcJob &job = jobs[blockIdx.y >> 1];
+  const int ch = blockIdx.y & 1, n = job.n;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= n) return;
+  const int32_t *own = ch ? job.s[1] : job.s[0];
+  const double *ss = (ch ? job.ss[1] : job.ss[0]) + (size_t)t * LPC_N;
+  double pm = 0.;
+  if (t > 0) {  // weights as left by Update(t-1); before the first update they are all zero
+    const double *se = (ch ? job.serr[1] : job.serr[0]) + (size_t)(t - 1) * LPC_N;
+    double w[LPC_N];
+    double wsum = 0;
+#pragma unroll
+    for (int i = 0; i < LPC_N; i++) {
+      const double tt = 10000. / (se[i] + 0.0001);
+      w[i] = tt * tt;
+      wsum += w[i];
+    }
+    if (wsum > 0) {
+#pragma unroll
+      for (int i = 0; i < LPC_N; i++) w[i] /= wsum;
+    }
+#pragma unroll
+    for (int i = 0; i < LPC_N; i++) pm += w[i] * ss[i];
+  }
+  const double v = (double)own[t];
+  (ch ? job.p[1] : job.p[0])[t] = pm;
+  (ch ? job.x1[1] : job.x1[0])[t] = v - pm;  // val[ch][1] = val[ch][0] - p[0] (profile.cpp:144)
+}
+
+// Fast profile: LPC2::Predict (lpc.h:261-267) + residual (profile.cpp:30-31), thread per t
+__global__ __launch_bounds__(256) void k_pred2(const LpcJob *__restrict__ jobs) {
+  const LpcJob &job = jobs[blockIdx.y >> 1];
+  const int ch = blockIdx.y & 1, n = job.n;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= n) return;
+  const int32_t *own = ch ? job.s[1] : job.s[0], *oth = ch ? job.s[0] : job.s[1];
+  const int lagb = (ch == 0) ? 1 : 0;
+  const int k = lpc_sol_index<32>(ch ? job.fail[1] : job.fail[0], t);
+  double p = 0.;
+  if (k >= 0) {
+    const double *sol = (ch ? job.sol[1] : job.sol[0]) + (size_t)k * LPC_N;
+    for (int i = 0; i < LPC_N; i++) p += sol[i] * lpc_hist(own, oth, lagb, i, t);
+  }
+  const int32_t e = (int32_t)((double)own[t] - round(p));
+  const int32_t ue = s2u(e);
+  int32_t *eo = ch ? job.e[1] : job.e[0], *uo = ch ? job.u[1] : job.u[0];
+  if (eo) eo[t] = e;
+  if (uo) uo[t] = ue;
+  if (job.umax) atomicMax(&job.umax[ch], ue);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -520,14 +643,22 @@ extern "C" int sacopt_launch_lms(int S, int D, const LmsJob *jobs, int njobs, co
   else return 1;
   return hipGetLastError() != hipSuccess;
 }
-extern "C" int sacopt_launch_lpc3(const LpcJob *jobs, int njobs, hipStream_t st) {
-  if (njobs <= 0) return 0;
-  hipLaunchKernelGGL(k_lpc<false>, dim3(njobs, 2), dim3(64), 0, st, jobs);
+extern "C" int sacopt_launch_lpc3(const LpcJob *jobs, int njobs, int max_n, hipStream_t st) {
+  if (njobs <= 0 || max_n <= 0) return 0;
+  const int max_snap = max_n / 8;
+  hipLaunchKernelGGL(k_cov<8>, dim3(njobs, 2), dim3(384), 0, st, jobs);
+  if (max_snap) hipLaunchKernelGGL(k_chol<false>, dim3(max_snap, 2 * njobs), dim3(64), 0, st, jobs);
+  hipLaunchKernelGGL(k_ssum, dim3((unsigned)(((long long)max_n * LPC_N + 255) / 256), 2 * njobs), dim3(256), 0, st, jobs);
+  hipLaunchKernelGGL(k_serr, dim3(njobs, 2), dim3(64), 0, st, jobs);
+  hipLaunchKernelGGL(k_pm, dim3((max_n + 255) / 256, 2 * njobs), dim3(256), 0, st, jobs);
   return hipGetLastError() != hipSuccess;
 }
-extern "C" int sacopt_launch_lpc2(const LpcJob *jobs, int njobs, hipStream_t st) {
-  if (njobs <= 0) return 0;
-  hipLaunchKernelGGL(k_lpc<true>, dim3(njobs, 2), dim3(64), 0, st, jobs);
+extern "C" int sacopt_launch_lpc2(const LpcJob *jobs, int njobs, int max_n, hipStream_t st) {
+  if (njobs <= 0 || max_n <= 0) return 0;
+  const int max_snap = max_n / 32;
+  hipLaunchKernelGGL(k_cov<32>, dim3(njobs, 2), dim3(384), 0, st, jobs);
+  if (max_snap) hipLaunchKernelGGL(k_chol<true>, dim3(max_snap, 2 * njobs), dim3(64), 0, st, jobs);
+  hipLaunchKernelGGL(k_pred2, dim3((max_n + 255) / 256, 2 * njobs), dim3(256), 0, st, jobs);
   return hipGetLastError() != hipSuccess;
 }
 extern "C" int sacopt_launch_mix(int ns, const MixJob *jobs, int njobs, hipStream_t st) {

@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <map>
 #include <string>
 #include <vector>
@@ -20,8 +21,8 @@
 
 extern "C" {
 int sacopt_launch_lms(int S, int D, const LmsJob *jobs, int njobs, const float *tab, int bits, hipStream_t st);
-int sacopt_launch_lpc3(const LpcJob *jobs, int njobs, hipStream_t st);
-int sacopt_launch_lpc2(const LpcJob *jobs, int njobs, hipStream_t st);
+int sacopt_launch_lpc3(const LpcJob *jobs, int njobs, int max_n, hipStream_t st);
+int sacopt_launch_lpc2(const LpcJob *jobs, int njobs, int max_n, hipStream_t st);
 int sacopt_launch_mix(int ns, const MixJob *jobs, int njobs, hipStream_t st);
 int sacopt_launch_cost(const CostJob *jobs, int njobs, const int *pow2_bits, hipStream_t st);
 int sacopt_launch_meanrms(const int32_t *e, int n, double *out, hipStream_t st);
@@ -319,6 +320,32 @@ static size_t chain_bytes(const ProfDesc &pd, int n) {
   return (size_t)(pd.nlms + 1) * 4 * nd + 4 * ni + 256;
 }
 
+// LPC scratch (covariance snapshots, solutions, all-orders sums, running errors) for one chain
+static size_t lpc_scratch_bytes(int type, int n) {
+  const int ks = (type == SACOPT_PROFILE_FAST) ? 32 : 8;
+  const size_t nsnap = (size_t)n / ks;
+  auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  size_t per_ch = al(nsnap * 324 * 8) + al(nsnap * (type == SACOPT_PROFILE_FAST ? 24 : 300) * 8) + al(nsnap * 4 + 4);
+  if (type != SACOPT_PROFILE_FAST) per_ch += 2 * al((size_t)n * 24 * 8);
+  return 2 * per_ch + 1024;
+}
+static int lpc_scratch_alloc(sacopt_ctx *c, int type, LpcJob &j) {
+  const int ks = (type == SACOPT_PROFILE_FAST) ? 32 : 8;
+  j.nsnap = j.n / ks;
+  for (int k = 0; k < 2; k++) {
+    j.snap[k] = arena_alloc<double>(c, (size_t)j.nsnap * 324);
+    j.sol[k] = arena_alloc<double>(c, (size_t)j.nsnap * (type == SACOPT_PROFILE_FAST ? 24 : 300));
+    j.fail[k] = arena_alloc<int32_t>(c, (size_t)j.nsnap + 1);
+    if (!j.snap[k] || !j.sol[k] || !j.fail[k]) { c->err = "device arena exhausted (LPC scratch)"; return 1; }
+    if (type != SACOPT_PROFILE_FAST) {
+      j.ss[k] = arena_alloc<double>(c, (size_t)j.n * 24);
+      j.serr[k] = arena_alloc<double>(c, (size_t)j.n * 24);
+      if (!j.ss[k] || !j.serr[k]) { c->err = "device arena exhausted (LPC scratch)"; return 1; }
+    }
+  }
+  return 0;
+}
+
 // Run all chains through the cascade, re-using memoised stage outputs. `want_u`: also write s2u.
 static int eval_chains(sacopt_ctx *c, const ProfDesc &pd, const std::vector<DevFrame> &fr, std::vector<Chain> &chains,
                        Memo &memo) {
@@ -366,9 +393,19 @@ static int eval_chains(sacopt_ctx *c, const ProfDesc &pd, const std::vector<DevF
         j.n = f.n;
         jobs.push_back(j);
       }
-      LpcJob *dj;
-      if (upload(c, jobs, &dj)) return 1;
-      if (sacopt_launch_lpc2(dj, (int)jobs.size(), c->st)) { c->err = "k_lpc2 launch failed"; return 1; }
+      LpcJob *dj = arena_alloc<LpcJob>(c, jobs.size());
+      if (!dj) { c->err = "device arena exhausted"; return 1; }
+      const size_t mark = c->used;  // scratch is released once the stage has been enqueued (stream order)
+      int max_n = 0;
+      for (LpcJob &j : jobs) {
+        if (lpc_scratch_alloc(c, pd.type, j)) return 1;
+        max_n = j.n > max_n ? j.n : max_n;
+        HIPCK(c, hipMemsetAsync(j.umax, 0, 8, c->st));
+      }
+      HIPCK(c, hipMemcpyAsync(dj, jobs.data(), jobs.size() * sizeof(LpcJob), hipMemcpyHostToDevice, c->st));
+      HIPCK(c, hipStreamSynchronize(c->st));  // jobs vector is host-local
+      if (sacopt_launch_lpc2(dj, (int)jobs.size(), max_n, c->st)) { c->err = "LPC2 launch failed"; return 1; }
+      c->used = mark;
     } else if (s == 0) {
       std::vector<LpcJob> jobs;
       for (int ci : todo) {
@@ -379,12 +416,20 @@ static int eval_chains(sacopt_ctx *c, const ProfDesc &pd, const std::vector<DevF
         for (int k = 0; k < 2; k++) { j.s[k] = f.s[k] + f.from; j.p[k] = ch.sb[0].p[k]; j.x1[k] = ch.sb[0].xn[k]; }
         j.alpha = ch.coefs[0];
         j.n = f.n;
-        j.pad = 0;
         jobs.push_back(j);
       }
-      LpcJob *dj;
-      if (upload(c, jobs, &dj)) return 1;
-      if (sacopt_launch_lpc3(dj, (int)jobs.size(), c->st)) { c->err = "k_lpc3 launch failed"; return 1; }
+      LpcJob *dj = arena_alloc<LpcJob>(c, jobs.size());
+      if (!dj) { c->err = "device arena exhausted"; return 1; }
+      const size_t mark = c->used;
+      int max_n = 0;
+      for (LpcJob &j : jobs) {
+        if (lpc_scratch_alloc(c, pd.type, j)) return 1;
+        max_n = j.n > max_n ? j.n : max_n;
+      }
+      HIPCK(c, hipMemcpyAsync(dj, jobs.data(), jobs.size() * sizeof(LpcJob), hipMemcpyHostToDevice, c->st));
+      HIPCK(c, hipStreamSynchronize(c->st));
+      if (sacopt_launch_lpc3(dj, (int)jobs.size(), max_n, c->st)) { c->err = "LPC3 launch failed"; return 1; }
+      c->used = mark;
     } else if (s <= pd.nlms) {
       const StageDesc &sd = pd.lms[s - 1];
       std::vector<LmsJob> jobs;
@@ -489,7 +534,8 @@ extern "C" int sacopt_predict_stereo_frames(sacopt_ctx *c, int profile, int nfra
   size_t need = 1 << 20;
   for (int f = 0; f < nframes; f++) {
     const int nn = n ? n[f] : frames[f].numsamples - (from ? from[f] : 0);
-    need += chain_bytes(pd, nn > 0 ? nn : 0) + 2 * (((size_t)frames[f].numsamples * 4 + 255) & ~(size_t)255) + 4096;
+    need += chain_bytes(pd, nn > 0 ? nn : 0) + 2 * (((size_t)frames[f].numsamples * 4 + 255) & ~(size_t)255) + 4096 +
+            lpc_scratch_bytes(pd.type, nn > 0 ? nn : 0) + sizeof(LpcJob) + 256;
   }
   if (arena_reserve(c, need)) return 1;
   HIPCK(c, hipEventRecord(c->ev0, c->st));
@@ -568,7 +614,7 @@ extern "C" int sacopt_get_costs(sacopt_ctx *c, int profile, int nframes, const s
   for (int f = 0; f < nframes; f++) {
     const int nn = n ? n[f] : frames[f].numsamples - (from ? from[f] : 0);
     need += (size_t)ncand * chain_bytes(pd, nn > 0 ? nn : 0) + 2 * (((size_t)frames[f].numsamples * 4 + 255) & ~(size_t)255) + 4096 +
-            (size_t)ncand * 64;
+            (size_t)ncand * (64 + lpc_scratch_bytes(pd.type, nn > 0 ? nn : 0) + sizeof(LpcJob) + 256);
   }
   if (arena_reserve(c, need)) return 1;
   HIPCK(c, hipEventRecord(c->ev0, c->st));
@@ -625,7 +671,11 @@ extern "C" int sacopt_optimize_frames(sacopt_ctx *c, int profile, int nframes, c
   for (int f = 0; f < nframes; f++) {
     wn[f] = frames[f].numsamples / 8;
     from[f] = (frames[f].numsamples - wn[f]) / 2;
-    need += total_cand * (chain_bytes(pd, wn[f]) + 256) + 2 * (((size_t)frames[f].numsamples * 4 + 255) & ~(size_t)255) + 8192;
+    size_t lpc_jobs = 1;  // most LPC jobs of this frame alive in one round
+    for (int i = 0; i < ncoef_loop; i++)
+      if (pd.nprefix[0] > i && grid[i].size() > lpc_jobs) lpc_jobs = grid[i].size();
+    need += total_cand * (chain_bytes(pd, wn[f]) + 256 + sizeof(LpcJob)) + 2 * (((size_t)frames[f].numsamples * 4 + 255) & ~(size_t)255) + 8192 +
+            lpc_jobs * (lpc_scratch_bytes(pd.type, wn[f]) + 256);
   }
   if (arena_reserve(c, need)) return 1;
   HIPCK(c, hipEventRecord(c->ev0, c->st));
@@ -771,7 +821,8 @@ extern "C" int sacopt_lms_pair(sacopt_ctx *c, int S, int D, double mu1, double m
   HIPCK(c, hipEventCreate(&a));
   HIPCK(c, hipEventCreate(&b));
   HIPCK(c, hipEventRecord(a, c->st));
-  if (sacopt_launch_lms(S, D, dj, 1, c->d_tab, c->bits, c->st)) { c->err = "unsupported (S,D) or launch failure"; return 1; }
+  { const char *dbg = getenv("SACOPT_DBG"); int dm = dbg ? atoi(dbg) : 0;
+  if (sacopt_launch_lms(S, D, dj, 1, c->d_tab, c->bits | (dm << 8), c->st)) { c->err = "unsupported (S,D) or launch failure"; return 1; } }
   HIPCK(c, hipEventRecord(b, c->st));
   c->lms_ev.push_back({a, b});
   if (copy_out(c, p0, j.p[0], (size_t)n * 8) || copy_out(c, p1, j.p[1], (size_t)n * 8)) return 1;
@@ -783,17 +834,18 @@ extern "C" int sacopt_lpc3_pair(sacopt_ctx *c, double alpha, const int32_t *s0, 
   if (begin_call(c)) return 1;
   if (n < 0 || (n && (!s0 || !s1 || !p0 || !p1))) { c->err = "bad arguments"; return 1; }
   if (!n) return 0;
-  if (arena_reserve(c, (size_t)n * 8 * 6 + (1 << 16))) return 1;
+  if (arena_reserve(c, (size_t)n * 8 * 6 + lpc_scratch_bytes(SACOPT_PROFILE_HIGH, n) + (1 << 16))) return 1;
   HIPCK(c, hipEventRecord(c->ev0, c->st));
   LpcJob j;
   memset(&j, 0, sizeof(j));
   if (to_dev(c, s0, n, &j.s[0]) || to_dev(c, s1, n, &j.s[1])) return 1;
   for (int k = 0; k < 2; k++) { j.p[k] = arena_alloc<double>(c, n); j.x1[k] = arena_alloc<double>(c, n); }
   j.alpha = alpha; j.n = n;
+  if (lpc_scratch_alloc(c, SACOPT_PROFILE_HIGH, j)) return 1;
   std::vector<LpcJob> jobs = {j};
   LpcJob *dj;
   if (upload(c, jobs, &dj)) return 1;
-  if (sacopt_launch_lpc3(dj, 1, c->st)) { c->err = "k_lpc3 launch failed"; return 1; }
+  if (sacopt_launch_lpc3(dj, 1, n, c->st)) { c->err = "LPC3 launch failed"; return 1; }
   if (copy_out(c, p0, j.p[0], (size_t)n * 8) || copy_out(c, p1, j.p[1], (size_t)n * 8)) return 1;
   return end_timing(c);
 }
