@@ -90,6 +90,14 @@ int sacopt_optimize_frames(sacopt_ctx *ctx, int profile, int nframes, const saco
                            const double *prof, int ncoef_loop, double *best, double *trace,
                            int max_rows, int32_t *rows);
 
+/* ---- FrameCoder::Predict  src/codec.cpp:442-461, with the Optimize call of :455-456 enabled ---- */
+/* Per frame: Optimize(optprofile) (if ncoef_loop > 0; selected values -> best[f*ncoef..]) and
+ * PredictStereoFrame(baseprofile, 0, 1, 0, numsamples) -> out[f]. The stream is coded with the
+ * base profile exactly as the reference does (:459), so the two are independent and run
+ * concurrently on the GPU. prof = ncoef x {vmin,vmax,vdef} (NULL = base profile). */
+int sacopt_encode_frames(sacopt_ctx *ctx, int profile, int nframes, const sacopt_frame *frames,
+                         const double *prof, int ncoef_loop, double *best, sacopt_residuals *out);
+
 /* ---- CostGolomb::Calc / CostMeanRMS::Calc on caller-supplied residuals (src/codec.cpp:302-339) - */
 int sacopt_cost_golomb(sacopt_ctx *ctx, const int32_t *buf, int n, double *state_inout, double *cost);
 int sacopt_cost_meanrms(sacopt_ctx *ctx, const int32_t *buf, int n, double *cost);

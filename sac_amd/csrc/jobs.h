@@ -13,7 +13,9 @@ struct LmsJob {
   double *p[2];        // stage predictions p[k]
   double *xn[2];       // next stage inputs val[ch][k+1] = x - p (may be NULL)
   double mu1, mu2;
-  int32_t n, pad;
+  int32_t n;           // samples to process in this launch: absolute times [t0, t0+n)
+  int32_t t0;          // chunk start (multiple of LMS_CHUNK); arrays are indexed by absolute time
+  double *state;       // w/eg carried between chunks ([2][R][NT] doubles); NULL = single launch
 };
 
 struct LpcJob {
@@ -42,8 +44,10 @@ struct MixJob {
   int32_t *u[2];           // s2u_error[ch]       (may be NULL)
   int32_t *umax;           // [2] max s2u          (may be NULL)
   double alpha;
-  int32_t n, pad;
+  int32_t n, t0;           // absolute times [t0, t0+n)
+  double *state;           // RLS P,w (+max) carried between chunks ([2][MIX_STATE] doubles); NULL = single launch
 };
+#define MIX_STATE 24
 
 struct CostJob {
   const int32_t *const *bufs;  // nbuf residual buffers in CostGolomb call order (cand0 ch0, cand0 ch1, ...)

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
   __shared__ float tab[RSQ_LDS_MAX];
 
   const LmsJob job = jobs[blockIdx.x];
-  const int tid = threadIdx.x, n = job.n;
+  const int tid = threadIdx.x, t0 = job.t0, tend = job.t0 + job.n;
   const int dbg = bits >> 8;  // DEBUG ablation flags
   bits &= 0xff;
   for (int i = tid; i < (2 << bits); i += NT) tab[i] = gtab[i];
@@ -127,6 +127,17 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
     paddr[r] = c * T + i;
     w[r] = 0.; eg[r] = 0.;
     if (!valid[r]) { hsel[r] = 0; hoff[r] = 0; paddr[r] = 0; }
+    if (t0 > 0 && job.state) {  // resume: weights / gradient energies of the previous chunk
+      w[r] = job.state[r * NT + tid];
+      eg[r] = job.state[(R + r) * NT + tid];
+    }
+  }
+  if (t0 > 0) {  // history before the chunk comes straight from the stage's input arrays
+    for (int idx = tid; idx < 2 * (RL - CH); idx += NT) {
+      const int c = idx / (RL - CH), tau = t0 - (RL - CH) + (idx - c * (RL - CH));
+      const double *xs = c ? job.x[1] : job.x[0];
+      ring[c][tau & M] = (tau >= 0) ? xs[tau] : 0.;
+    }
   }
   const int lane = tid & 63, wave = tid >> 6;
   const int mk = lane >> 4, mc = lane & 15;
@@ -134,12 +145,12 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
   // Chains 0/1 are the two channels; chains 2..15 just repeat them (harmless, keeps loads unconditional).
   const double *mp = &prods[mc & 1][mk];
 
-  for (int t = 0; t < n; t++) {
+  for (int t = t0; t < tend; t++) {
     if ((t & (CH - 1)) == 0) {
       for (int idx = tid; idx < 2 * CH; idx += NT) {
         const int c = idx / CH, k = idx - c * CH, tau = t + k;
         const double *xs = c ? job.x[1] : job.x[0];
-        ring[c][tau & M] = (tau < n) ? xs[tau] : 0.;
+        ring[c][tau & M] = (tau < tend) ? xs[tau] : 0.;
       }
       __syncthreads();
     }
@@ -186,6 +197,13 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
         eg[r] = 0.95 * eg[r] + (1.0 - 0.95) * (grad * grad);
         w[r] += (mu[r] * grad * rsq_emul(eg[r] + 0.001, tab, bits));
       }
+    }
+  }
+  if (job.state) {
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      job.state[r * NT + tid] = w[r];
+      job.state[(R + r) * NT + tid] = eg[r];
     }
   }
 }
@@ -458,7 +476,7 @@ __global__ __launch_bounds__(64) void k_mix(const MixJob *__restrict__ jobs, int
   const int gid = blockIdx.x * 64 + threadIdx.x;
   if (gid >= 2 * njobs) return;
   const MixJob &job = jobs[gid >> 1];
-  const int ch = gid & 1, n = job.n;
+  const int ch = gid & 1, t0 = job.t0, tend = job.t0 + job.n;
   const double alpha = job.alpha;
   const int32_t *s = job.s[ch];
   const double *p0 = job.p0[ch], *x1 = job.x1[ch];
@@ -474,7 +492,17 @@ __global__ __launch_bounds__(64) void k_mix(const MixJob *__restrict__ jobs, int
     for (int j = 0; j < NS; j++) P[i][j] = (i == j) ? 1. : 0.;
   }
   int32_t umax = 0;
-  for (int t = 0; t < n; t++) {
+  double *stp = job.state ? job.state + ch * MIX_STATE : nullptr;
+  if (t0 > 0 && stp) {
+#pragma unroll
+    for (int i = 0; i < NS; i++) {
+      w[i] = stp[i];
+#pragma unroll
+      for (int j = 0; j < NS; j++) P[i][j] = stp[4 + i * NS + j];
+    }
+    umax = (int32_t)stp[20];
+  }
+  for (int t = t0; t < tend; t++) {
     double hist[NS];
     hist[0] = pk[0][t];
 #pragma unroll
@@ -523,6 +551,15 @@ __global__ __launch_bounds__(64) void k_mix(const MixJob *__restrict__ jobs, int
     for (int i = 0; i < NS; i++) w[i] = w[i] + dv * kk[i];
   }
   if (job.umax) job.umax[ch] = umax;
+  if (stp) {
+#pragma unroll
+    for (int i = 0; i < NS; i++) {
+      stp[i] = w[i];
+#pragma unroll
+      for (int j = 0; j < NS; j++) stp[4 + i * NS + j] = P[i][j];
+    }
+    stp[20] = (double)umax;
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -633,6 +670,13 @@ __global__ void k_rls(const double *pv, const double *val, int len, double alpha
 // ------------------------------------------------------------------------------------------
 // host-callable launchers (sacopt.cpp is compiled by the host compiler pass of the same TU set)
 // ------------------------------------------------------------------------------------------
+extern "C" int sacopt_lms_state_doubles(int S, int D) {  // 2 * R * NT of the matching k_lms instance
+  if (S == 1280 && D == 640) return 2 * 4 * 1024;
+  if (S == 256 && D == 128) return 2 * 3 * 256;
+  if (S == 32 && D == 16) return 2 * 2 * 64;
+  if (S == 8 && D == 4) return 2 * 1 * 64;
+  return 0;
+}
 extern "C" int sacopt_launch_lms(int S, int D, const LmsJob *jobs, int njobs, const float *tab, int bits,
                                  hipStream_t st) {
   if (njobs <= 0) return 0;

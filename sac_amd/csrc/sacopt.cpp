@@ -20,6 +20,7 @@
 #include "jobs.h"
 
 extern "C" {
+int sacopt_lms_state_doubles(int S, int D);
 int sacopt_launch_lms(int S, int D, const LmsJob *jobs, int njobs, const float *tab, int bits, hipStream_t st);
 int sacopt_launch_lpc3(const LpcJob *jobs, int njobs, int max_n, hipStream_t st);
 int sacopt_launch_lpc2(const LpcJob *jobs, int njobs, int max_n, hipStream_t st);
@@ -34,6 +35,8 @@ static thread_local std::string g_create_error;
 struct sacopt_ctx {
   int device = 0;
   hipStream_t st = nullptr;
+  hipStream_t sA = nullptr, sB = nullptr;  // final-pass pipeline: dominant LMS stage / everything else
+  std::vector<hipEvent_t> pipe_ev;         // events of the last call's pipeline
   float *d_tab = nullptr;
   int bits = 0;
   int *d_pow2 = nullptr;
@@ -195,7 +198,8 @@ extern "C" int sacopt_create(int device, const float *rsqrt_tab, int rsqrt_bits,
   c->bits = bits;
   auto fail = [&](const char *what) { g_create_error = what; delete c; return 1; };
   if (hipSetDevice(device) != hipSuccess) return fail("hipSetDevice failed");
-  if (hipStreamCreate(&c->st) != hipSuccess) return fail("hipStreamCreate failed");
+  if (hipStreamCreate(&c->st) != hipSuccess || hipStreamCreate(&c->sA) != hipSuccess || hipStreamCreate(&c->sB) != hipSuccess)
+    return fail("hipStreamCreate failed");
   if (hipMalloc(&c->d_tab, sizeof(float) * (2 << bits)) != hipSuccess) return fail("hipMalloc(table) failed");
   if (hipMemcpy(c->d_tab, tab.data(), sizeof(float) * (2 << bits), hipMemcpyHostToDevice) != hipSuccess) return fail("table upload failed");
   int pw[32];
@@ -218,6 +222,9 @@ extern "C" void sacopt_destroy(sacopt_ctx *c) {
   if (c->arena) (void)hipFree(c->arena);
   if (c->d_tab) (void)hipFree(c->d_tab);
   if (c->d_pow2) (void)hipFree(c->d_pow2);
+  for (hipEvent_t e : c->pipe_ev) (void)hipEventDestroy(e);
+  if (c->sA) (void)hipStreamDestroy(c->sA);
+  if (c->sB) (void)hipStreamDestroy(c->sB);
   if (c->st) (void)hipStreamDestroy(c->st);
   delete c;
 }
@@ -266,6 +273,8 @@ static int begin_call(sacopt_ctx *c) {
   c->err.clear();
   for (auto &p : c->lms_ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   c->lms_ev.clear();
+  for (hipEvent_t e : c->pipe_ev) (void)hipEventDestroy(e);
+  c->pipe_ev.clear();
   c->total_ms = c->lms_ms = 0;
   c->lms_launches = 0;
   c->lms_units = 0;
@@ -344,6 +353,12 @@ static int lpc_scratch_alloc(sacopt_ctx *c, int type, LpcJob &j) {
     }
   }
   return 0;
+}
+
+// job tables + carried state of the pipelined pass for one chain of n samples
+static size_t pipe_bytes(int n) {
+  const size_t nchunk = (size_t)n / (44 * LMS_CHUNK) + 1;
+  return nchunk * (4 * (sizeof(LmsJob) + 256) + sizeof(MixJob) + 256) + 16 * 1024 * 8 + 8192;
 }
 
 // Run all chains through the cascade, re-using memoised stage outputs. `want_u`: also write s2u.
@@ -440,7 +455,8 @@ static int eval_chains(sacopt_ctx *c, const ProfDesc &pd, const std::vector<DevF
         j.mu1 = ch.coefs[sd.c1];
         j.mu2 = ch.coefs[sd.c2];
         j.n = fr[ch.frame].n;
-        j.pad = 0;
+        j.t0 = 0;
+        j.state = nullptr;
         jobs.push_back(j);
       }
       LmsJob *dj;
@@ -484,6 +500,169 @@ static int eval_chains(sacopt_ctx *c, const ProfDesc &pd, const std::vector<DevF
     }
   }
   return 0;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Full-frame pass, pipelined. A frame is one long time-serial chain per stage; stages are
+// feed-forward, so the chain is cut into chunks of PIPE_CHUNK samples and stage s works on chunk
+// k while stage s-1 works on chunk k+1 (stage state -- LMS weights/energies, RLS P/w -- is
+// carried through small state buffers, histories are re-read from the stage inputs). The
+// dominant LMS stage runs on stream sA, all other stages on sB; the critical path is the
+// dominant stage alone. Everything is enqueued without host synchronisation, so a caller can
+// overlap it with work on c->st (the optimizer rounds). Results are identical to eval_chains.
+// `done` receives an event recorded when the last stage has finished.
+#define PIPE_CHUNK (44 * LMS_CHUNK) /* 22528 samples */
+static int final_pass_enqueue(sacopt_ctx *c, const ProfDesc &pd, const std::vector<DevFrame> &fr, std::vector<Chain> &chains,
+                              hipEvent_t *done) {
+  const int nstage = pd.nlms + 2, last = pd.nlms + 1;
+  const int nch = (int)chains.size();
+  int max_n = 0;
+  for (Chain &ch : chains) {
+    const int n = fr[ch.frame].n;
+    max_n = n > max_n ? n : max_n;
+    for (int s = 0; s < nstage; s++) {
+      StageBuf b;
+      if (s != last) {
+        for (int k = 0; k < 2; k++) {
+          b.p[k] = arena_alloc<double>(c, n);
+          b.xn[k] = arena_alloc<double>(c, n);
+          if (!b.p[k] || !b.xn[k]) { c->err = "device arena exhausted"; return 1; }
+        }
+      } else {
+        for (int k = 0; k < 2; k++) {
+          b.e[k] = arena_alloc<int32_t>(c, n);
+          b.u[k] = arena_alloc<int32_t>(c, n);
+          if (!b.e[k] || !b.u[k]) { c->err = "device arena exhausted"; return 1; }
+        }
+        b.umax = arena_alloc<int32_t>(c, 2);
+        if (!b.umax) { c->err = "device arena exhausted"; return 1; }
+      }
+      ch.sb[s] = b;
+    }
+  }
+  const int nchunk = (max_n + PIPE_CHUNK - 1) / PIPE_CHUNK;
+  // ---- all job tables, built and uploaded up front
+  std::vector<LpcJob> lpc(nch);
+  for (int i = 0; i < nch; i++) {
+    const Chain &ch = chains[i];
+    const DevFrame &f = fr[ch.frame];
+    LpcJob &j = lpc[i];
+    memset(&j, 0, sizeof(j));
+    for (int k = 0; k < 2; k++) { j.s[k] = f.s[k] + f.from; j.p[k] = ch.sb[0].p[k]; j.x1[k] = ch.sb[0].xn[k]; }
+    j.alpha = ch.coefs[0];
+    j.n = f.n;
+    if (lpc_scratch_alloc(c, pd.type, j)) return 1;  // stays allocated for the whole call
+  }
+  LpcJob *d_lpc;
+  if (upload(c, lpc, &d_lpc)) return 1;
+  std::vector<std::vector<LmsJob *>> d_lms(pd.nlms, std::vector<LmsJob *>(nchunk, nullptr));
+  std::vector<std::vector<int>> n_lms(pd.nlms, std::vector<int>(nchunk, 0));
+  std::vector<MixJob *> d_mix(nchunk, nullptr);
+  std::vector<int> n_mix(nchunk, 0);
+  std::vector<long long> units(nchunk, 0);
+  std::vector<std::vector<double *>> lms_state(pd.nlms, std::vector<double *>(nch, nullptr));
+  std::vector<double *> mix_state(nch, nullptr);
+  for (int i = 0; i < nch; i++) {
+    for (int q = 0; q < pd.nlms; q++) {
+      lms_state[q][i] = arena_alloc<double>(c, sacopt_lms_state_doubles(pd.lms[q].S, pd.lms[q].D));
+      if (!lms_state[q][i]) { c->err = "device arena exhausted"; return 1; }
+    }
+    mix_state[i] = arena_alloc<double>(c, 2 * MIX_STATE);
+    if (!mix_state[i]) { c->err = "device arena exhausted"; return 1; }
+  }
+  for (int k = 0; k < nchunk; k++) {
+    const int t0 = k * PIPE_CHUNK;
+    for (int q = 0; q < pd.nlms; q++) {
+      std::vector<LmsJob> jobs;
+      for (int i = 0; i < nch; i++) {
+        const Chain &ch = chains[i];
+        const int n = fr[ch.frame].n;
+        if (t0 >= n) continue;
+        LmsJob j;
+        for (int h = 0; h < 2; h++) { j.x[h] = ch.sb[q].xn[h]; j.p[h] = ch.sb[q + 1].p[h]; j.xn[h] = ch.sb[q + 1].xn[h]; }
+        j.mu1 = ch.coefs[pd.lms[q].c1];
+        j.mu2 = ch.coefs[pd.lms[q].c2];
+        j.t0 = t0;
+        j.n = (n - t0 < PIPE_CHUNK) ? n - t0 : PIPE_CHUNK;
+        j.state = lms_state[q][i];
+        jobs.push_back(j);
+        if (q == 0) units[k] += j.n;
+      }
+      n_lms[q][k] = (int)jobs.size();
+      if (!jobs.empty() && upload(c, jobs, &d_lms[q][k])) return 1;
+    }
+    std::vector<MixJob> jobs;
+    for (int i = 0; i < nch; i++) {
+      const Chain &ch = chains[i];
+      const DevFrame &f = fr[ch.frame];
+      if (t0 >= f.n && !(k == 0 && f.n == 0)) continue;
+      MixJob j;
+      memset(&j, 0, sizeof(j));
+      for (int h = 0; h < 2; h++) {
+        j.s[h] = f.s[h] + f.from;
+        j.p0[h] = ch.sb[0].p[h];
+        j.x1[h] = ch.sb[0].xn[h];
+        for (int q = 0; q < pd.nlms; q++) j.pk[q][h] = ch.sb[q + 1].p[h];
+        j.e[h] = ch.sb[last].e[h];
+        j.u[h] = ch.sb[last].u[h];
+      }
+      j.umax = ch.sb[last].umax;
+      j.alpha = ch.coefs[pd.cmix];
+      j.t0 = t0;
+      j.n = (f.n - t0 < PIPE_CHUNK) ? f.n - t0 : PIPE_CHUNK;
+      j.state = mix_state[i];
+      jobs.push_back(j);
+    }
+    n_mix[k] = (int)jobs.size();
+    if (!jobs.empty() && upload(c, jobs, &d_mix[k])) return 1;
+  }
+  // ---- enqueue
+  auto new_event = [&](hipEvent_t *e) -> int {
+    HIPCK(c, hipEventCreateWithFlags(e, hipEventDisableTiming));
+    c->pipe_ev.push_back(*e);
+    return 0;
+  };
+  hipEvent_t ev_in, ev_lpc;
+  if (new_event(&ev_in) || new_event(&ev_lpc)) return 1;
+  HIPCK(c, hipEventRecord(ev_in, c->st));  // inputs + job tables were staged on c->st
+  HIPCK(c, hipStreamWaitEvent(c->sB, ev_in, 0));
+  HIPCK(c, hipStreamWaitEvent(c->sA, ev_in, 0));
+  if (sacopt_launch_lpc3(d_lpc, nch, max_n, c->sB)) { c->err = "LPC3 launch failed"; return 1; }
+  HIPCK(c, hipEventRecord(ev_lpc, c->sB));
+  HIPCK(c, hipStreamWaitEvent(c->sA, ev_lpc, 0));
+  for (int k = 0; k < nchunk; k++) {
+    hipEvent_t a, b, e1;
+    HIPCK(c, hipEventCreate(&a));
+    HIPCK(c, hipEventCreate(&b));
+    HIPCK(c, hipEventRecord(a, c->sA));
+    if (sacopt_launch_lms(pd.lms[0].S, pd.lms[0].D, d_lms[0][k], n_lms[0][k], c->d_tab, c->bits, c->sA)) { c->err = "k_lms launch failed"; return 1; }
+    HIPCK(c, hipEventRecord(b, c->sA));
+    c->lms_ev.push_back({a, b});
+    c->lms_units += units[k];
+    if (new_event(&e1)) return 1;
+    HIPCK(c, hipEventRecord(e1, c->sA));
+    HIPCK(c, hipStreamWaitEvent(c->sB, e1, 0));
+    for (int q = 1; q < pd.nlms; q++)
+      if (sacopt_launch_lms(pd.lms[q].S, pd.lms[q].D, d_lms[q][k], n_lms[q][k], c->d_tab, c->bits, c->sB)) { c->err = "k_lms launch failed"; return 1; }
+    if (sacopt_launch_mix(pd.nlms, d_mix[k], n_mix[k], c->sB)) { c->err = "k_mix launch failed"; return 1; }
+  }
+  if (new_event(done)) return 1;
+  HIPCK(c, hipEventRecord(*done, c->sB));
+  return 0;
+}
+
+// Full-frame (or any window) pass for all chains; long windows go through the pipeline.
+static int run_final_pass(sacopt_ctx *c, const ProfDesc &pd, const std::vector<DevFrame> &fr, std::vector<Chain> &chains,
+                          hipEvent_t *done) {
+  *done = nullptr;
+  int max_n = 0;
+  for (const Chain &ch : chains) max_n = fr[ch.frame].n > max_n ? fr[ch.frame].n : max_n;
+  if (pd.type == SACOPT_PROFILE_FAST || max_n <= 2 * PIPE_CHUNK) {
+    Memo memo;
+    return eval_chains(c, pd, fr, chains, memo);
+  }
+  return final_pass_enqueue(c, pd, fr, chains, done);
 }
 
 // Stage input frames: device pointers are used in place, host pointers are copied into the arena.
@@ -535,7 +714,7 @@ extern "C" int sacopt_predict_stereo_frames(sacopt_ctx *c, int profile, int nfra
   for (int f = 0; f < nframes; f++) {
     const int nn = n ? n[f] : frames[f].numsamples - (from ? from[f] : 0);
     need += chain_bytes(pd, nn > 0 ? nn : 0) + 2 * (((size_t)frames[f].numsamples * 4 + 255) & ~(size_t)255) + 4096 +
-            lpc_scratch_bytes(pd.type, nn > 0 ? nn : 0) + sizeof(LpcJob) + 256;
+            lpc_scratch_bytes(pd.type, nn > 0 ? nn : 0) + sizeof(LpcJob) + 256 + pipe_bytes(nn > 0 ? nn : 0);
   }
   if (arena_reserve(c, need)) return 1;
   HIPCK(c, hipEventRecord(c->ev0, c->st));
@@ -546,8 +725,9 @@ extern "C" int sacopt_predict_stereo_frames(sacopt_ctx *c, int profile, int nfra
     chains[f].frame = f;
     for (int i = 0; i < pd.ncoef; i++) chains[f].coefs[i] = coefs ? coefs[(size_t)f * pd.ncoef + i] : base[3 * i + 2];
   }
-  Memo memo;
-  if (eval_chains(c, pd, fr, chains, memo)) return 1;
+  hipEvent_t done = nullptr;
+  if (run_final_pass(c, pd, fr, chains, &done)) return 1;
+  if (done) HIPCK(c, hipStreamWaitEvent(c->st, done, 0));
   const int last = (pd.type == SACOPT_PROFILE_FAST) ? 0 : pd.nlms + 1;
   std::vector<int32_t> um(2 * (size_t)nframes);
   for (int f = 0; f < nframes; f++) {
@@ -640,21 +820,10 @@ extern "C" int sacopt_get_costs(sacopt_ctx *c, int profile, int nframes, const s
   return end_timing(c);
 }
 
-extern "C" int sacopt_optimize_frames(sacopt_ctx *c, int profile, int nframes, const sacopt_frame *frames, const double *prof_in,
-                                      int ncoef_loop, double *best, double *trace, int max_rows, int32_t *rows_out) {
-  if (!c) return 1;
-  if (begin_call(c)) return 1;
-  ProfDesc pd;
-  if (!get_prof(profile, &pd)) { c->err = "unknown profile"; return 1; }
-  if (nframes < 0 || (nframes && (!frames || !best))) { c->err = "bad arguments"; return 1; }
-  if (ncoef_loop < 0 || ncoef_loop > pd.ncoef) { c->err = "ncoef_loop exceeds the profile's coefficient count (the reference would index past coefs[], codec.cpp:389)"; return 1; }
-  if (!nframes) return 0;
-  double prof[3 * SACOPT_MAX_COEFS];
-  sacopt_base_profile(profile, prof);
-  if (prof_in) memcpy(prof, prof_in, sizeof(double) * 3 * pd.ncoef);
-  // candidate grids, generated exactly as the reference loop does (codec.cpp:392-404)
-  std::vector<std::vector<double>> grid(ncoef_loop);
-  size_t total_cand = 1;
+// candidate grids, generated exactly as the reference loop does (codec.cpp:392-404)
+static int build_grid(sacopt_ctx *c, const double *prof, int ncoef_loop, std::vector<std::vector<double>> &grid, size_t *total_cand) {
+  grid.assign(ncoef_loop, std::vector<double>());
+  *total_cand = 1;
   for (int i = 0; i < ncoef_loop; i++) {
     double x = prof[3 * i];
     const double xinc = (prof[3 * i + 1] - prof[3 * i]) / 10.;
@@ -663,28 +832,25 @@ extern "C" int sacopt_optimize_frames(sacopt_ctx *c, int profile, int nframes, c
       x += xinc;
       if (grid[i].size() > 64) { c->err = "degenerate coefficient range (grid does not terminate)"; return 1; }
     }
-    total_cand += grid[i].size();
+    *total_cand += grid[i].size();
   }
-  // windows (codec.cpp:356-359)
-  std::vector<int32_t> from(nframes), wn(nframes);
-  size_t need = 1 << 20;
-  for (int f = 0; f < nframes; f++) {
-    wn[f] = frames[f].numsamples / 8;
-    from[f] = (frames[f].numsamples - wn[f]) / 2;
-    size_t lpc_jobs = 1;  // most LPC jobs of this frame alive in one round
-    for (int i = 0; i < ncoef_loop; i++)
-      if (pd.nprefix[0] > i && grid[i].size() > lpc_jobs) lpc_jobs = grid[i].size();
-    need += total_cand * (chain_bytes(pd, wn[f]) + 256 + sizeof(LpcJob)) + 2 * (((size_t)frames[f].numsamples * 4 + 255) & ~(size_t)255) + 8192 +
-            lpc_jobs * (lpc_scratch_bytes(pd.type, wn[f]) + 256);
-  }
-  if (arena_reserve(c, need)) return 1;
-  HIPCK(c, hipEventRecord(c->ev0, c->st));
-  std::vector<DevFrame> fr;
-  if (stage_frames(c, nframes, frames, from.data(), wn.data(), fr)) return 1;
+  return 0;
+}
+// arena bytes Optimize needs for one frame with an n-sample window
+static size_t optimize_bytes(const ProfDesc &pd, int ncoef_loop, const std::vector<std::vector<double>> &grid, size_t total_cand, int wn) {
+  size_t lpc_jobs = 1;  // most LPC jobs of this frame alive in one round
+  for (int i = 0; i < ncoef_loop; i++)
+    if (pd.nprefix[0] > i && grid[i].size() > lpc_jobs) lpc_jobs = grid[i].size();
+  return total_cand * (chain_bytes(pd, wn) + 256 + sizeof(LpcJob)) + 8192 + lpc_jobs * (lpc_scratch_bytes(pd.type, wn) + 256);
+}
+
+// The search itself, on frames already staged (fr[f].from/n = optimisation window), all on c->st.
+static int optimize_core(sacopt_ctx *c, const ProfDesc &pd, const std::vector<DevFrame> &fr, const double *prof, int ncoef_loop,
+                         const std::vector<std::vector<double>> &grid, double *best, double *trace, int max_rows, int32_t *rows_out) {
+  const int nframes = (int)fr.size();
   std::vector<double> st(nframes, 0.);  // one CostGolomb instance per Optimize call (codec.cpp:364)
   double *d_state;
   if (upload(c, st, &d_state)) return 1;
-
   std::vector<std::vector<double>> cur(nframes, std::vector<double>(pd.ncoef));
   for (int f = 0; f < nframes; f++)
     for (int i = 0; i < pd.ncoef; i++) cur[f][i] = prof[3 * i + 2];
@@ -734,7 +900,102 @@ extern "C" int sacopt_optimize_frames(sacopt_ctx *c, int profile, int nframes, c
     memcpy(best + (size_t)f * pd.ncoef, cur[f].data(), 8 * pd.ncoef);
     if (rows_out) rows_out[f] = rows[f];
   }
+  return 0;
+}
+
+extern "C" int sacopt_optimize_frames(sacopt_ctx *c, int profile, int nframes, const sacopt_frame *frames, const double *prof_in,
+                                      int ncoef_loop, double *best, double *trace, int max_rows, int32_t *rows_out) {
+  if (!c) return 1;
+  if (begin_call(c)) return 1;
+  ProfDesc pd;
+  if (!get_prof(profile, &pd)) { c->err = "unknown profile"; return 1; }
+  if (nframes < 0 || (nframes && (!frames || !best))) { c->err = "bad arguments"; return 1; }
+  if (ncoef_loop < 0 || ncoef_loop > pd.ncoef) { c->err = "ncoef_loop exceeds the profile's coefficient count (the reference would index past coefs[], codec.cpp:389)"; return 1; }
+  if (!nframes) return 0;
+  double prof[3 * SACOPT_MAX_COEFS];
+  sacopt_base_profile(profile, prof);
+  if (prof_in) memcpy(prof, prof_in, sizeof(double) * 3 * pd.ncoef);
+  std::vector<std::vector<double>> grid;
+  size_t total_cand;
+  if (build_grid(c, prof, ncoef_loop, grid, &total_cand)) return 1;
+  std::vector<int32_t> from(nframes), wn(nframes);  // windows (codec.cpp:356-359)
+  size_t need = 1 << 20;
+  for (int f = 0; f < nframes; f++) {
+    wn[f] = frames[f].numsamples / 8;
+    from[f] = (frames[f].numsamples - wn[f]) / 2;
+    need += optimize_bytes(pd, ncoef_loop, grid, total_cand, wn[f]) + 2 * (((size_t)frames[f].numsamples * 4 + 255) & ~(size_t)255);
+  }
+  if (arena_reserve(c, need)) return 1;
+  HIPCK(c, hipEventRecord(c->ev0, c->st));
+  std::vector<DevFrame> fr;
+  if (stage_frames(c, nframes, frames, from.data(), wn.data(), fr)) return 1;
+  if (optimize_core(c, pd, fr, prof, ncoef_loop, grid, best, trace, max_rows, rows_out)) return 1;
   return end_timing(c);
+}
+
+// ------------------------------------------------------------------------------------------ FrameCoder::Predict
+// FrameCoder::Predict (src/codec.cpp:442-461) with the optimizer call of :455-456 enabled:
+// Optimize(optprofile) on the centre window and PredictStereoFrame(baseprofile,0,1,0,numsamples)
+// are independent ("ref+opt": the frame is coded with the base profile), so the full-frame pass
+// is enqueued on the pipeline streams first and runs underneath the optimizer rounds.
+extern "C" int sacopt_encode_frames(sacopt_ctx *c, int profile, int nframes, const sacopt_frame *frames, const double *prof_in,
+                                    int ncoef_loop, double *best, sacopt_residuals *out) {
+  if (!c) return 1;
+  if (begin_call(c)) return 1;
+  ProfDesc pd;
+  if (!get_prof(profile, &pd)) { c->err = "unknown profile"; return 1; }
+  if (nframes < 0 || (nframes && (!frames || !out || (ncoef_loop > 0 && !best)))) { c->err = "bad arguments"; return 1; }
+  if (ncoef_loop < 0 || ncoef_loop > pd.ncoef) { c->err = "ncoef_loop exceeds the profile's coefficient count (the reference would index past coefs[], codec.cpp:389)"; return 1; }
+  if (!nframes) return 0;
+  double prof[3 * SACOPT_MAX_COEFS];
+  sacopt_base_profile(profile, prof);
+  if (prof_in) memcpy(prof, prof_in, sizeof(double) * 3 * pd.ncoef);
+  std::vector<std::vector<double>> grid;
+  size_t total_cand = 0;
+  if (ncoef_loop > 0 && build_grid(c, prof, ncoef_loop, grid, &total_cand)) return 1;
+  size_t need = 1 << 20;
+  for (int f = 0; f < nframes; f++) {
+    const int ns = frames[f].numsamples;
+    if (ns < 0) { c->err = "negative numsamples"; return 1; }
+    need += chain_bytes(pd, ns) + 2 * (((size_t)ns * 4 + 255) & ~(size_t)255) + 4096 + lpc_scratch_bytes(pd.type, ns) + sizeof(LpcJob) + 256 + pipe_bytes(ns);
+    if (ncoef_loop > 0) need += optimize_bytes(pd, ncoef_loop, grid, total_cand, ns / 8);
+  }
+  if (arena_reserve(c, need)) return 1;
+  HIPCK(c, hipEventRecord(c->ev0, c->st));
+  std::vector<DevFrame> fr;
+  if (stage_frames(c, nframes, frames, nullptr, nullptr, fr)) return 1;
+  // full-frame pass with the base profile (codec.cpp:459)
+  std::vector<Chain> chains(nframes);
+  for (int f = 0; f < nframes; f++) {
+    chains[f].frame = f;
+    for (int i = 0; i < pd.ncoef; i++) chains[f].coefs[i] = prof[3 * i + 2];
+  }
+  hipEvent_t done = nullptr;
+  if (run_final_pass(c, pd, fr, chains, &done)) return 1;
+  if (ncoef_loop > 0) {  // Optimize on the centre window (codec.cpp:356-359)
+    std::vector<DevFrame> win = fr;
+    for (DevFrame &w : win) { w.n = w.numsamples / 8; w.from = (w.numsamples - w.n) / 2; }
+    if (optimize_core(c, pd, win, prof, ncoef_loop, grid, best, nullptr, 0, nullptr)) return 1;
+  }
+  if (done) HIPCK(c, hipStreamWaitEvent(c->st, done, 0));
+  const int last = (pd.type == SACOPT_PROFILE_FAST) ? 0 : pd.nlms + 1;
+  std::vector<int32_t> um(2 * (size_t)nframes);
+  for (int f = 0; f < nframes; f++) {
+    const StageBuf &b = chains[f].sb[last];
+    const size_t bytes = (size_t)fr[f].n * 4;
+    if (copy_out(c, out[f].err0, b.e[0], bytes) || copy_out(c, out[f].err1, b.e[1], bytes) ||
+        copy_out(c, out[f].s2u0, b.u[0], bytes) || copy_out(c, out[f].s2u1, b.u[1], bytes))
+      return 1;
+    HIPCK(c, hipMemcpyAsync(&um[2 * f], b.umax, 8, hipMemcpyDeviceToHost, c->st));
+  }
+  if (end_timing(c)) return 1;
+  for (int f = 0; f < nframes; f++) {
+    out[f].maxbpn[0] = ilog2(um[2 * f]);
+    out[f].maxbpn[1] = ilog2(um[2 * f + 1]);
+    out[f].maxbpn[2] = out[f].maxbpn[3] = -1;
+    if (out[f].map0 || out[f].map1) { c->err = "s2u_error_map outputs are not implemented yet"; return 1; }
+  }
+  return 0;
 }
 
 // ------------------------------------------------------------------------------------------ cost on caller residuals
@@ -813,7 +1074,7 @@ extern "C" int sacopt_lms_pair(sacopt_ctx *c, int S, int D, double mu1, double m
   if (to_dev(c, x0, n, &j.x[0]) || to_dev(c, x1, n, &j.x[1])) return 1;
   j.p[0] = arena_alloc<double>(c, n);
   j.p[1] = arena_alloc<double>(c, n);
-  j.mu1 = mu1; j.mu2 = mu2; j.n = n;
+  j.mu1 = mu1; j.mu2 = mu2; j.n = n; j.t0 = 0; j.state = nullptr;
   std::vector<LmsJob> jobs = {j};
   LmsJob *dj;
   if (upload(c, jobs, &dj)) return 1;

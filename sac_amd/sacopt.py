@@ -47,6 +47,7 @@ def lib():
                                        C.c_void_p, C.c_void_p, C.c_void_p]
         L.sacopt_optimize_frames.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                              C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.sacopt_encode_frames.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.sacopt_cost_golomb.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.sacopt_cost_meanrms.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.sacopt_lms_pair.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p,
@@ -59,7 +60,7 @@ def lib():
 
 
 EXPORTS = ["sacopt_create", "sacopt_destroy", "sacopt_last_error", "sacopt_probe_rsqrt", "sacopt_base_profile",
-           "sacopt_predict_stereo_frames", "sacopt_get_costs", "sacopt_optimize_frames", "sacopt_cost_golomb",
+           "sacopt_predict_stereo_frames", "sacopt_get_costs", "sacopt_optimize_frames", "sacopt_encode_frames", "sacopt_cost_golomb",
            "sacopt_cost_meanrms", "sacopt_lms_pair", "sacopt_lpc3_pair", "sacopt_rls_run", "sacopt_last_timing"]
 
 
@@ -187,6 +188,32 @@ class Context:
         self._ck(lib().sacopt_optimize_frames(self._h, profile, nf, arr, _p(pf), ncoef_loop, _p(best), _p(trace),
                                               max_rows, _p(rows)))
         return best, [trace[f, :min(rows[f], max_rows)].copy() for f in range(nf)], rows
+
+    def encode(self, profile, frames, prof=None, ncoef_loop=None, device_out=None):
+        """FrameCoder::Predict with Optimize enabled: returns (best[nframes,ncoef], residual dicts)."""
+        nf = len(frames)
+        arr, keep = self._frames(frames)
+        nc = NCOEF[profile]
+        if ncoef_loop is None:
+            ncoef_loop = nc
+        pf = None if prof is None else np.ascontiguousarray(prof, dtype=np.float64)
+        best = np.zeros((nf, nc))
+        res = (Residuals * max(nf, 1))()
+        outs = []
+        for i in range(nf):
+            if device_out is None:
+                d = {k: np.zeros(arr[i].numsamples, np.int32) for k in ("e0", "e1", "u0", "u1")}
+                res[i].err0, res[i].err1 = d["e0"].ctypes.data, d["e1"].ctypes.data
+                res[i].s2u0, res[i].s2u1 = d["u0"].ctypes.data, d["u1"].ctypes.data
+            else:
+                d = {}
+                res[i].err0, res[i].err1 = device_out[i].get("e0"), device_out[i].get("e1")
+                res[i].s2u0, res[i].s2u1 = device_out[i].get("u0"), device_out[i].get("u1")
+            outs.append(d)
+        self._ck(lib().sacopt_encode_frames(self._h, profile, nf, arr, _p(pf), ncoef_loop, _p(best), res))
+        for i in range(nf):
+            outs[i]["maxbpn"] = np.array(list(res[i].maxbpn), np.int32)
+        return best, outs
 
     def cost_golomb(self, buf, state=0.0):
         st = np.array([state], np.float64)

@@ -74,6 +74,19 @@ def test_predict_vs_oracle(ctx, oracle, prof, seed, n):
         assert np.array_equal(out[k], ref[k]), k
 
 
+@pytest.mark.parametrize("prof", [1, 2])
+def test_predict_pipelined_long_frames(ctx, oracle, prof):
+    # frames longer than two pipeline chunks (2 x 22528) take the chunk-pipelined path with
+    # carried stage state; ragged lengths make the last chunks differ per frame
+    frames = [stereo_clip(50, 50000), stereo_clip(51, 46001)]
+    outs = ctx.predict(prof, frames)
+    for (L, R), o in zip(frames, outs):
+        ref = oracle.predict(prof, L, R, maps=True)
+        for k in ("e0", "e1", "u0", "u1"):
+            assert np.array_equal(o[k], ref[k]), k
+        assert np.array_equal(o["maxbpn"][:2], ref["maxbpn"][:2])
+
+
 def test_predict_edge_cases(ctx, oracle):
     # empty frame, 1-sample frame, ragged batch, silence, full-scale
     L, R = stereo_clip(34, 700)
@@ -133,3 +146,15 @@ def test_optimize_vs_oracle_ragged(ctx, oracle):
     for f, (L, R) in enumerate(frames):
         ob, ot = oracle.optimize(2, L, R)
         assert same_bits(best[f], ob) and same_bits(traces[f], ot), f
+
+
+def test_encode_frames_overlapped(ctx, oracle):
+    # FrameCoder::Predict with Optimize enabled: optimizer rounds and the pipelined full-frame pass
+    # run concurrently on the GPU; both must still match the oracle bit for bit
+    frames = [stereo_clip(60, 48000), stereo_clip(61, 46000)]
+    best, outs = ctx.encode(2, frames)
+    for f, (L, R) in enumerate(frames):
+        ob, _ = oracle.optimize(2, L, R)
+        assert same_bits(best[f], ob), f
+        ref = oracle.predict(2, L, R)
+        assert np.array_equal(outs[f]["e0"], ref["e0"]) and np.array_equal(outs[f]["e1"], ref["e1"]), f
