@@ -80,6 +80,49 @@ __device__ __forceinline__ double mfma_chain_lds(uint32_t addr) {
 }
 #undef MF
 
+
+// One MFMA adder pass over 16 segments x 120 products: chain j (segment j) starts from the value
+// its D-layout lanes hold in `acc`, lane (k = lane>>4, j = lane&15) feeds term 4s+k of segment j
+// at step s (30 steps, 32 bytes apart from `addr`). Returns D: lanes 16*i+4*blk+{0..3} hold chain
+// 4*blk+i. Straight-line, operands of the next group of 8 always in flight.
+#define MF(areg) "v_mfma_f64_4x4x4_4b_f64 %0, " areg ", %2, %0\n s_nop 3\n"
+__device__ __forceinline__ double mfma_pass30(uint32_t addr, double acc) {
+  double one = 1.0;
+  double a0, a1, a2, a3, a4, a5, a6, a7, b0, b1, b2, b3, b4, b5, b6, b7;
+  asm volatile(
+      "ds_read_b64 %3, %1\n ds_read_b64 %4, %1 offset:32\n ds_read_b64 %5, %1 offset:64\n ds_read_b64 %6, %1 offset:96\n"
+      "ds_read_b64 %7, %1 offset:128\n ds_read_b64 %8, %1 offset:160\n ds_read_b64 %9, %1 offset:192\n ds_read_b64 %10, %1 offset:224\n"
+      "ds_read_b64 %11, %1 offset:256\n ds_read_b64 %12, %1 offset:288\n ds_read_b64 %13, %1 offset:320\n ds_read_b64 %14, %1 offset:352\n"
+      "ds_read_b64 %15, %1 offset:384\n ds_read_b64 %16, %1 offset:416\n ds_read_b64 %17, %1 offset:448\n ds_read_b64 %18, %1 offset:480\n"
+      "s_waitcnt lgkmcnt(8)\n s_nop 1\n"
+      MF("%3") MF("%4") MF("%5") MF("%6") MF("%7") MF("%8") MF("%9") MF("%10")
+      "ds_read_b64 %3, %1 offset:512\n ds_read_b64 %4, %1 offset:544\n ds_read_b64 %5, %1 offset:576\n ds_read_b64 %6, %1 offset:608\n"
+      "ds_read_b64 %7, %1 offset:640\n ds_read_b64 %8, %1 offset:672\n ds_read_b64 %9, %1 offset:704\n ds_read_b64 %10, %1 offset:736\n"
+      "s_waitcnt lgkmcnt(8)\n s_nop 1\n"
+      MF("%11") MF("%12") MF("%13") MF("%14") MF("%15") MF("%16") MF("%17") MF("%18")
+      "ds_read_b64 %11, %1 offset:768\n ds_read_b64 %12, %1 offset:800\n ds_read_b64 %13, %1 offset:832\n ds_read_b64 %14, %1 offset:864\n"
+      "ds_read_b64 %15, %1 offset:896\n ds_read_b64 %16, %1 offset:928\n"
+      "s_waitcnt lgkmcnt(6)\n s_nop 1\n"
+      MF("%3") MF("%4") MF("%5") MF("%6") MF("%7") MF("%8") MF("%9") MF("%10")
+      "s_waitcnt lgkmcnt(0)\n s_nop 1\n"
+      MF("%11") MF("%12") MF("%13") MF("%14") MF("%15") MF("%16")
+      "s_nop 7\n"
+      : "+v"(acc), "+v"(addr), "+v"(one), "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(a4), "=&v"(a5), "=&v"(a6),
+        "=&v"(a7), "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3), "=&v"(b4), "=&v"(b5), "=&v"(b6), "=&v"(b7)
+      :
+      : "memory");
+  return acc;
+}
+#undef MF
+
+// ulp of a normal double as a power of two (0 for zero / tiny values: no candidates then)
+__device__ __forceinline__ double ulp_pow2(double x, double *inv) {
+  const int e = (__double2hiint(x) >> 20) & 0x7ff;
+  if (e < 64 || e > 1900) { *inv = 0.; return 0.; }
+  *inv = __hiloint2double((1023 + 1075 - e) << 20, 0);  // 2^(52 - (e-1023))
+  return __hiloint2double((e - 52) << 20, 0);           // 2^(e-1023-52)
+}
+
 // ------------------------------------------------------------------------------------------
 // LMSADA2 stereo pair (src/pred/nlms.h:96-139), driven as StereoHigh/StereoNormal drive it
 // (src/profile.cpp:126-148,176-186):
@@ -88,7 +131,7 @@ __device__ __forceinline__ double mfma_chain_lds(uint32_t addr) {
 // is a ring of stage inputs in LDS (shifts of nlms.h:109,130 become index arithmetic), products
 // go to LDS in the operand layout of the f64 MFMA, wave 0 sums them on the matrix pipe.
 // ------------------------------------------------------------------------------------------
-template <int S, int D, int NT, int R, int RL>
+template <int S, int D, int NT, int R, int RL, bool SPEC>
 __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, const float *__restrict__ gtab,
                                             int bits) {
   constexpr int T = S + D, T4 = T / 4, M = RL - 1, CH = LMS_CHUNK;
@@ -99,6 +142,8 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
   __shared__ double prods[2][T];
   __shared__ double ring[2][RL];
   __shared__ double predv[2];
+  // speculative exact summation (SPEC): 16 segments x 4 candidate start values per channel
+  __shared__ double sBase[2][17], sU[2][17], sInvU[2][17], sOut[2][16][4];
   __shared__ float tab[RSQ_LDS_MAX];
 
   const LmsJob job = jobs[blockIdx.x];
@@ -145,7 +190,10 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
   // Chains 0/1 are the two channels; chains 2..15 just repeat them (harmless, keeps loads unconditional).
   const double *mp = &prods[mc & 1][mk];
 
+  long long tmr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tq = 0;  // DEBUG phase timers (dbg & 128)
+#define STAMP(i) do { if (dbg & 128) { long long now_ = __builtin_amdgcn_s_memtime(); tmr[i] += now_ - tq; tq = now_; } } while (0)
   for (int t = t0; t < tend; t++) {
+    if (dbg & 128) tq = __builtin_amdgcn_s_memtime();
     if ((t & (CH - 1)) == 0) {
       for (int idx = tid; idx < 2 * CH; idx += NT) {
         const int c = idx / CH, k = idx - c * CH, tau = t + k;
@@ -162,7 +210,106 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
       if (valid[r] && !(dbg & 4)) (&prods[0][0])[paddr[r]] = w[r] * h[r];
     }
     __syncthreads();
+    STAMP(0);
     // ---- pred = 0.; for i: pred += w[i]*hist[i]  -- strict order, on the matrix pipe
+    if constexpr (SPEC) {
+      // The 1920-term chain is cut into 16 segments of 120. A segment's exact output depends on
+      // its exact input, but the map input -> output is a shift for inputs on the same binade
+      // grid (and a staircase across binade rises), so: (P0) segment sums from 0 give guesses of
+      // the segment inputs; (P1) every segment is summed exactly from 4 candidate inputs around
+      // its guess; (walk) the true chain is followed through the tables (integer arithmetic in
+      // units of ulp, periodic extension outside a table); (P2) every segment is re-summed from
+      // the walked input and must reproduce the next walked input bit for bit -- by induction
+      // from x_0 = 0 the result then IS the sequential sum. A mismatch pins the first wrong
+      // boundary to the value P2 just computed and repeats (progress >= 1 segment per round).
+      static_assert(T == 1920 && NT == 512, "SPEC is laid out for the (1280,640) stage with 8 waves");
+      // waves 0..7: channel = wave&1, candidate = wave>>1, so that the two channels' lead waves
+      // (0 and 1) and each channel's four candidate waves sit on different SIMDs
+      const int sc = wave & 1, sm = wave >> 1;
+      const int jA = lane & 15, kA = lane >> 4, jD = 4 * ((lane >> 2) & 3) + (lane >> 4);
+      const int dl = 16 * (lane & 3) + 4 * ((lane >> 2) & 3);  // D-layout lane of chain (lane & 15)
+      const uint32_t paddr = (uint32_t)(uintptr_t)&prods[sc][jA * 120 + kA];
+      const int j16 = lane & 15;
+      double gA = 0., gBase = 0., gU = 0., gIU = 0.;  // lanes 0..15 (and their mod-16 copies): per-boundary values
+      if (sm == 0 && !(dbg & 64)) {  // P0: segment sums from zero -> guesses of the segment inputs
+        const double a = mfma_pass30(paddr, 0.);
+        gA = __shfl(a, dl);  // lane l now holds A_(l&15)
+        double sh = gA;      // exclusive prefix over the 16 segments (any order: only a guess)
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { const double v = __shfl_up(sh, o, 16); if (j16 >= o) sh += v; }
+        sh -= gA;  // inclusive -> exclusive (exact for j = 1: A_0 + A_1 - A_1 may round, so fix it up)
+        const double a0 = bcast(gA, 0);
+        if (j16 == 1) sh = a0;
+        if (j16 == 0) sh = 0.;
+        gU = ulp_pow2(sh, &gIU);
+        gBase = sh - 2. * gU;
+        if (lane < 16) { sBase[sc][lane] = gBase; sU[sc][lane] = gU; sInvU[sc][lane] = gIU; }
+      }
+      __syncthreads();
+      STAMP(1);
+      if (!(dbg & 32)) {  // P1: exact segment sums from candidate inputs base + m*ulp
+        const double st = sBase[sc][jD] + (double)sm * sU[sc][jD];
+        sOut[sc][jD][sm] = mfma_pass30(paddr, st);
+      }
+      __syncthreads();
+      STAMP(2);
+      if (sm == 0) {
+        // table entry (j, m): next segment's offset (in its ulps) if segment j's input offset is m
+        const int tj = lane >> 2, tm = lane & 3;
+        int dv = 0, ks = 0;
+        if (tj < 15) {
+          dv = (int)((sOut[sc][tj][tm] - sBase[sc][tj + 1]) * sInvU[sc][tj + 1]);
+          const int e0 = (__double2hiint(sU[sc][tj]) >> 20) & 0x7ff, e1 = (__double2hiint(sU[sc][tj + 1]) >> 20) & 0x7ff;
+          ks = (e0 && e1) ? e0 - e1 : 0;
+        }
+        const double a0 = bcast(gA, 0);
+        int first = 1;  // boundary from which the walk (re)starts
+        int del = __builtin_amdgcn_readfirstlane((bcast(gU, 1) != 0.) ? 2 : 0);  // x_1 = A_0 = guess_1
+        double x = 0.;  // lane j (< 16): walked input of segment j
+        if (lane == 1) x = a0;
+        double res = 0.;
+        for (int guard = 0; guard < 17; guard++) {
+          // ---- walk: a scalar integer chain (del is wave-uniform), no memory
+          int myd = 0, d = del;
+#pragma unroll
+          for (int j = 1; j < 15; j++) {
+            if (j >= first) {
+              const int m = d & 3, q = d - m;
+              const int dn = __builtin_amdgcn_readlane(dv, 4 * j + m);
+              const int kk = __builtin_amdgcn_readlane(ks, 4 * j);
+              d = dn + (kk >= 0 ? (q << (kk & 31)) : (q >> ((-kk) & 31)));
+              if (lane == j + 1) myd = d;
+            }
+          }
+          if (lane > first && lane < 16) x = gBase + (double)myd * gU;
+          STAMP(3);
+          // ---- P2: verify every boundary
+          const double xs = __shfl(x, jD);
+          res = mfma_pass30(paddr, xs);
+          const double xn = __shfl(x, jD < 15 ? jD + 1 : 15);
+          const bool bad = (jD < 15) && (__double_as_longlong(res) != __double_as_longlong(xn));
+          const unsigned long long mask = __ballot(bad);
+          STAMP(4);
+          if (dbg & 128) tmr[6] += 1;
+          if (mask == 0ull || (dbg & 16)) break;
+          int f = 0;  // first failing segment (D-layout lane of chain j: 16*(j&3) + 4*(j>>2))
+          while (f < 15 && !((mask >> (16 * (f & 3) + 4 * (f >> 2))) & 1ull)) f++;
+          f = __builtin_amdgcn_readfirstlane(f);
+          const double xt = bcast(res, 16 * (f & 3) + 4 * (f >> 2));  // exact x_{f+1}
+          if (lane == f + 1) x = xt;
+          first = f + 1;
+          const double bq = bcast(gBase, f + 1), iq = bcast(gIU, f + 1);
+          del = __builtin_amdgcn_readfirstlane((int)((xt - bq) * iq));
+        }
+        if (lane == 60) {  // chain 15 lives in D lanes 60..63
+          predv[sc] = res;
+          const double xc = ring[sc][t & M];
+          double *po = sc ? job.p[1] : job.p[0], *xo = sc ? job.xn[1] : job.xn[0];
+          po[t] = res;
+          if (xo) xo[t] = xc - res;  // CalcError (profile.cpp:141-148)
+        }
+      }
+    } else
     if (wave == 0) {
       double acc = 0.;
       if (dbg & 1) acc = mp[t & 7]; else
@@ -186,6 +333,7 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
       }
     }
     __syncthreads();
+    STAMP(5);
     // ---- Update (nlms.h:114-129)
     const double e0 = ring[0][t & M] - predv[0];
     const double e1 = ring[1][t & M] - predv[1];
@@ -198,7 +346,10 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
         w[r] += (mu[r] * grad * rsq_emul(eg[r] + 0.001, tab, bits));
       }
     }
+    STAMP(7);
   }
+  if ((dbg & 128) && tid == 0) for (int i = 0; i < 8; i++) job.p[0][i] = (double)tmr[i];
+#undef STAMP
   if (job.state) {
 #pragma unroll
     for (int r = 0; r < R; r++) {
@@ -680,10 +831,13 @@ extern "C" int sacopt_lms_state_doubles(int S, int D) {  // 2 * R * NT of the ma
 extern "C" int sacopt_launch_lms(int S, int D, const LmsJob *jobs, int njobs, const float *tab, int bits,
                                  hipStream_t st) {
   if (njobs <= 0) return 0;
-  if (S == 1280 && D == 640) hipLaunchKernelGGL((k_lms<1280, 640, 1024, 4, 2048>), dim3(njobs), dim3(1024), 0, st, jobs, tab, bits);
-  else if (S == 256 && D == 128) hipLaunchKernelGGL((k_lms<256, 128, 256, 3, 1024>), dim3(njobs), dim3(256), 0, st, jobs, tab, bits);
-  else if (S == 32 && D == 16) hipLaunchKernelGGL((k_lms<32, 16, 64, 2, 1024>), dim3(njobs), dim3(64), 0, st, jobs, tab, bits);
-  else if (S == 8 && D == 4) hipLaunchKernelGGL((k_lms<8, 4, 64, 1, 1024>), dim3(njobs), dim3(64), 0, st, jobs, tab, bits);
+  if (S == 1280 && D == 640) {
+    if ((bits >> 8) & 8) hipLaunchKernelGGL((k_lms<1280, 640, 1024, 4, 2048, false>), dim3(njobs), dim3(1024), 0, st, jobs, tab, bits);
+    else hipLaunchKernelGGL((k_lms<1280, 640, 512, 8, 2048, true>), dim3(njobs), dim3(512), 0, st, jobs, tab, bits);
+  }
+  else if (S == 256 && D == 128) hipLaunchKernelGGL((k_lms<256, 128, 256, 3, 1024, false>), dim3(njobs), dim3(256), 0, st, jobs, tab, bits);
+  else if (S == 32 && D == 16) hipLaunchKernelGGL((k_lms<32, 16, 64, 2, 1024, false>), dim3(njobs), dim3(64), 0, st, jobs, tab, bits);
+  else if (S == 8 && D == 4) hipLaunchKernelGGL((k_lms<8, 4, 64, 1, 1024, false>), dim3(njobs), dim3(64), 0, st, jobs, tab, bits);
   else return 1;
   return hipGetLastError() != hipSuccess;
 }
