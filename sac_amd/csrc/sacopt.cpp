@@ -36,6 +36,7 @@ struct sacopt_ctx {
   int device = 0;
   hipStream_t st = nullptr;
   hipStream_t sA = nullptr, sB = nullptr;  // final-pass pipeline: dominant LMS stage / everything else
+  hipStream_t sC = nullptr;                // follower stages of the optimizer rounds
   std::vector<hipEvent_t> pipe_ev;         // events of the last call's pipeline
   float *d_tab = nullptr;
   int bits = 0;
@@ -200,6 +201,14 @@ extern "C" int sacopt_create(int device, const float *rsqrt_tab, int rsqrt_bits,
   if (hipSetDevice(device) != hipSuccess) return fail("hipSetDevice failed");
   if (hipStreamCreate(&c->st) != hipSuccess || hipStreamCreate(&c->sA) != hipSuccess || hipStreamCreate(&c->sB) != hipSuccess)
     return fail("hipStreamCreate failed");
+  {
+    // HIP multiplexes same-priority streams onto a small pool of in-order hardware queues (3 usable here);
+    // a 4th normal-priority stream would share a queue with the pre-enqueued full-frame pipeline and
+    // serialise behind it. Priorities have their own queue pools, so the follower stream takes another level.
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    if (hipStreamCreateWithPriority(&c->sC, hipStreamDefault, hi) != hipSuccess) return fail("hipStreamCreateWithPriority failed");
+  }
   if (hipMalloc(&c->d_tab, sizeof(float) * (2 << bits)) != hipSuccess) return fail("hipMalloc(table) failed");
   if (hipMemcpy(c->d_tab, tab.data(), sizeof(float) * (2 << bits), hipMemcpyHostToDevice) != hipSuccess) return fail("table upload failed");
   int pw[32];
@@ -225,6 +234,7 @@ extern "C" void sacopt_destroy(sacopt_ctx *c) {
   for (hipEvent_t e : c->pipe_ev) (void)hipEventDestroy(e);
   if (c->sA) (void)hipStreamDestroy(c->sA);
   if (c->sB) (void)hipStreamDestroy(c->sB);
+  if (c->sC) (void)hipStreamDestroy(c->sC);
   if (c->st) (void)hipStreamDestroy(c->st);
   delete c;
 }
@@ -326,7 +336,7 @@ static std::string memo_key(int frame, int stage, const double *coefs, int ncoef
 // bytes of arena one chain needs for all its stages
 static size_t chain_bytes(const ProfDesc &pd, int n) {
   const size_t nd = ((size_t)n * 8 + 255) & ~(size_t)255, ni = ((size_t)n * 4 + 255) & ~(size_t)255;
-  return (size_t)(pd.nlms + 1) * 4 * nd + 4 * ni + 256;
+  return (size_t)(pd.nlms + 1) * 4 * nd + 4 * ni + 256 + 80 * 1024 + 4 * 5 * 512;  // + carried stage state + job tables
 }
 
 // LPC scratch (covariance snapshots, solutions, all-orders sums, running errors) for one chain
@@ -365,6 +375,7 @@ static size_t pipe_bytes(int n) {
 static int eval_chains(sacopt_ctx *c, const ProfDesc &pd, const std::vector<DevFrame> &fr, std::vector<Chain> &chains,
                        Memo &memo) {
   const int nstage = (pd.type == SACOPT_PROFILE_FAST) ? 1 : pd.nlms + 2;
+  std::vector<std::vector<int>> todo_s(nstage);
   for (int s = 0; s < nstage; s++) {
     std::vector<int> todo;  // chain indices that own a new buffer at this stage
     for (size_t ci = 0; ci < chains.size(); ci++) {
@@ -445,63 +456,129 @@ static int eval_chains(sacopt_ctx *c, const ProfDesc &pd, const std::vector<DevF
       HIPCK(c, hipStreamSynchronize(c->st));
       if (sacopt_launch_lpc3(dj, (int)jobs.size(), max_n, c->st)) { c->err = "LPC3 launch failed"; return 1; }
       c->used = mark;
-    } else if (s <= pd.nlms) {
-      const StageDesc &sd = pd.lms[s - 1];
-      std::vector<LmsJob> jobs;
-      for (int ci : todo) {
-        const Chain &ch = chains[ci];
-        LmsJob j;
-        for (int k = 0; k < 2; k++) { j.x[k] = ch.sb[s - 1].xn[k]; j.p[k] = ch.sb[s].p[k]; j.xn[k] = ch.sb[s].xn[k]; }
-        j.mu1 = ch.coefs[sd.c1];
-        j.mu2 = ch.coefs[sd.c2];
-        j.n = fr[ch.frame].n;
-        j.t0 = 0;
-        j.state = nullptr;
-        jobs.push_back(j);
-      }
-      LmsJob *dj;
-      if (upload(c, jobs, &dj)) return 1;
-      const bool dominant = (s == 1);  // longest LMS stage of the profile: timed for the roofline
-      hipEvent_t a = nullptr, b = nullptr;
-      if (dominant) {
-        HIPCK(c, hipEventCreate(&a));
-        HIPCK(c, hipEventCreate(&b));
-        HIPCK(c, hipEventRecord(a, c->st));
-      }
-      if (sacopt_launch_lms(sd.S, sd.D, dj, (int)jobs.size(), c->d_tab, c->bits, c->st)) { c->err = "k_lms launch failed"; return 1; }
-      if (dominant) {
-        HIPCK(c, hipEventRecord(b, c->st));
-        c->lms_ev.push_back({a, b});
-        for (const LmsJob &j : jobs) c->lms_units += j.n;
-      }
     } else {
-      std::vector<MixJob> jobs;
-      for (int ci : todo) {
-        const Chain &ch = chains[ci];
-        const DevFrame &f = fr[ch.frame];
-        MixJob j;
-        memset(&j, 0, sizeof(j));
-        for (int k = 0; k < 2; k++) {
-          j.s[k] = f.s[k] + f.from;
-          j.p0[k] = ch.sb[0].p[k];
-          j.x1[k] = ch.sb[0].xn[k];
-          for (int q = 0; q < pd.nlms; q++) j.pk[q][k] = ch.sb[q + 1].p[k];
-          j.e[k] = ch.sb[s].e[k];
-          j.u[k] = ch.sb[s].u[k];
-        }
-        j.umax = ch.sb[s].umax;
-        j.alpha = ch.coefs[pd.cmix];
-        j.n = f.n;
-        jobs.push_back(j);
-      }
-      MixJob *dj;
-      if (upload(c, jobs, &dj)) return 1;
-      if (sacopt_launch_mix(pd.nlms, dj, (int)jobs.size(), c->st)) { c->err = "k_mix launch failed"; return 1; }
+      todo_s[s] = todo;  // LMS stages and the mixer are launched below, pipelined over chunks
     }
+  }
+  if (pd.type == SACOPT_PROFILE_FAST) return 0;
+  int lead = 0;  // first stage that has work: it runs on c->st, the stages behind it on c->sC
+  for (int s = 1; s < nstage && !lead; s++)
+    if (!todo_s[s].empty()) lead = s;
+  if (!lead) return 0;
+  int max_n = 0;
+  for (int ci : todo_s[nstage - 1]) max_n = fr[chains[ci].frame].n > max_n ? fr[chains[ci].frame].n : max_n;
+  // windows long enough are cut into 4 chunks so that the stages overlap (stage state is carried)
+  const int chunk = (max_n >= 8 * LMS_CHUNK) ? ((max_n + 4 * LMS_CHUNK - 1) / (4 * LMS_CHUNK)) * LMS_CHUNK : (max_n > 0 ? max_n : 1);
+  const int nchunk = max_n > 0 ? (max_n + chunk - 1) / chunk : 1;
+  const bool carry = nchunk > 1;
+  std::vector<std::vector<double *>> state(nstage);
+  if (carry)
+    for (int s = lead; s < nstage; s++) {
+      const size_t nd = (s <= pd.nlms) ? (size_t)sacopt_lms_state_doubles(pd.lms[s - 1].S, pd.lms[s - 1].D) : 2 * MIX_STATE;
+      for (size_t q = 0; q < todo_s[s].size(); q++) {
+        double *p = arena_alloc<double>(c, nd);
+        if (!p) { c->err = "device arena exhausted"; return 1; }
+        state[s].push_back(p);
+      }
+    }
+  hipEvent_t ev_join = nullptr;
+  for (int k = 0; k < nchunk; k++) {
+    const int t0 = k * chunk;
+    // ---- job tables of every stage for this chunk, staged on c->st ahead of the launches
+    std::vector<void *> d_jobs(nstage, nullptr);
+    std::vector<int> n_jobs(nstage, 0);
+    long long units = 0;
+    for (int s = lead; s < nstage; s++) {
+      if (s <= pd.nlms) {
+        const StageDesc &sd = pd.lms[s - 1];
+        std::vector<LmsJob> jobs;
+        for (size_t q = 0; q < todo_s[s].size(); q++) {
+          const Chain &ch = chains[todo_s[s][q]];
+          const int n = fr[ch.frame].n;
+          if (t0 >= n && k != 0) continue;
+          LmsJob j;
+          for (int h = 0; h < 2; h++) { j.x[h] = ch.sb[s - 1].xn[h]; j.p[h] = ch.sb[s].p[h]; j.xn[h] = ch.sb[s].xn[h]; }
+          j.mu1 = ch.coefs[sd.c1];
+          j.mu2 = ch.coefs[sd.c2];
+          j.t0 = t0;
+          j.n = n - t0 < chunk ? (n - t0 > 0 ? n - t0 : 0) : chunk;
+          j.state = carry ? state[s][q] : nullptr;
+          jobs.push_back(j);
+          if (s == 1) units += j.n;
+        }
+        n_jobs[s] = (int)jobs.size();
+        LmsJob *dj = nullptr;
+        if (!jobs.empty() && upload(c, jobs, &dj)) return 1;
+        d_jobs[s] = dj;
+      } else {
+        std::vector<MixJob> jobs;
+        for (size_t q = 0; q < todo_s[s].size(); q++) {
+          const Chain &ch = chains[todo_s[s][q]];
+          const DevFrame &f = fr[ch.frame];
+          if (t0 >= f.n && k != 0) continue;
+          MixJob j;
+          memset(&j, 0, sizeof(j));
+          for (int h = 0; h < 2; h++) {
+            j.s[h] = f.s[h] + f.from;
+            j.p0[h] = ch.sb[0].p[h];
+            j.x1[h] = ch.sb[0].xn[h];
+            for (int q2 = 0; q2 < pd.nlms; q2++) j.pk[q2][h] = ch.sb[q2 + 1].p[h];
+            j.e[h] = ch.sb[s].e[h];
+            j.u[h] = ch.sb[s].u[h];
+          }
+          j.umax = ch.sb[s].umax;
+          j.alpha = ch.coefs[pd.cmix];
+          j.t0 = t0;
+          j.n = f.n - t0 < chunk ? (f.n - t0 > 0 ? f.n - t0 : 0) : chunk;
+          j.state = carry ? state[s][q] : nullptr;
+          jobs.push_back(j);
+        }
+        n_jobs[s] = (int)jobs.size();
+        MixJob *dj = nullptr;
+        if (!jobs.empty() && upload(c, jobs, &dj)) return 1;
+        d_jobs[s] = dj;
+      }
+    }
+    // ---- launches: lead stage on c->st, followers on c->sC behind an event
+    for (int s = lead; s < nstage; s++) {
+      hipStream_t st = (s == lead) ? c->st : c->sC;
+      if (n_jobs[s]) {
+        if (s <= pd.nlms) {
+          const StageDesc &sd = pd.lms[s - 1];
+          const bool dominant = (s == 1);  // longest LMS stage of the profile: timed for the roofline
+          hipEvent_t a = nullptr, b = nullptr;
+          if (dominant) {
+            HIPCK(c, hipEventCreate(&a));
+            HIPCK(c, hipEventCreate(&b));
+            HIPCK(c, hipEventRecord(a, st));
+          }
+          if (sacopt_launch_lms(sd.S, sd.D, (const LmsJob *)d_jobs[s], n_jobs[s], c->d_tab, c->bits, st)) { c->err = "k_lms launch failed"; return 1; }
+          if (dominant) {
+            HIPCK(c, hipEventRecord(b, st));
+            c->lms_ev.push_back({a, b});
+            c->lms_units += units;
+          }
+        } else {
+          if (sacopt_launch_mix(pd.nlms, (const MixJob *)d_jobs[s], n_jobs[s], st)) { c->err = "k_mix launch failed"; return 1; }
+        }
+      }
+      if (s == lead && lead < nstage - 1) {
+        hipEvent_t e;
+        HIPCK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->pipe_ev.push_back(e);
+        HIPCK(c, hipEventRecord(e, c->st));
+        HIPCK(c, hipStreamWaitEvent(c->sC, e, 0));
+      }
+    }
+  }
+  if (lead < nstage - 1) {  // join: c->st continues (cost kernel, copies) after the follower stages
+    HIPCK(c, hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+    c->pipe_ev.push_back(ev_join);
+    HIPCK(c, hipEventRecord(ev_join, c->sC));
+    HIPCK(c, hipStreamWaitEvent(c->st, ev_join, 0));
   }
   return 0;
 }
-
 
 // ---------------------------------------------------------------------------------------------
 // Full-frame pass, pipelined. A frame is one long time-serial chain per stage; stages are
