@@ -31,11 +31,11 @@ FP64_VECTOR_PEAK_TFLOPS = 78.6     # MI355X datasheet vector FP64
 
 def cpu_baseline(seconds_budget=20.0):
     """The reference's own Optimize + PredictStereoFrame (oracle/_ref, kind 'reference') or the C
-    restatement (kind 'port') on ONE host core, on a bounded sample: one frame of 32768 samples."""
+    restatement (kind 'port') on ONE host core, on a bounded sample: one frame of 131072 samples."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
     from sac_amd.synth import stereo_clip
-    n = 32768
+    n = 131072     # ~15-25 s on one core
     L, R = stereo_clip(1, n)
     if oracle_lib.have_ref():
         ref = oracle_lib.Ref()
