@@ -256,12 +256,17 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
       if (sm == 0) {
         // table entry (j, m): next segment's offset (in its ulps) if segment j's input offset is m
         const int tj = lane >> 2, tm = lane & 3;
-        int dv = 0, ks = 0;
+        int dv = 0, kl = 0, kr = 0;  // kl/kr: left/right shift converting segment tj's ulps into tj+1's
         if (tj < 15) {
           dv = (int)((sOut[sc][tj][tm] - sBase[sc][tj + 1]) * sInvU[sc][tj + 1]);
           const int e0 = (__double2hiint(sU[sc][tj]) >> 20) & 0x7ff, e1 = (__double2hiint(sU[sc][tj + 1]) >> 20) & 0x7ff;
-          ks = (e0 && e1) ? e0 - e1 : 0;
+          const int ks = (e0 && e1) ? e0 - e1 : 0;
+          kl = ks > 0 ? (ks < 31 ? ks : 31) : 0;
+          kr = ks < 0 ? (-ks < 31 ? -ks : 31) : 0;
         }
+        int skl[15], skr[15];  // wave-uniform copies (scalar registers), fixed for this sample
+#pragma unroll
+        for (int j = 1; j < 15; j++) { skl[j] = __builtin_amdgcn_readlane(kl, 4 * j); skr[j] = __builtin_amdgcn_readlane(kr, 4 * j); }
         const double a0 = bcast(gA, 0);
         int first = 1;  // boundary from which the walk (re)starts
         int del = __builtin_amdgcn_readfirstlane((bcast(gU, 1) != 0.) ? 2 : 0);  // x_1 = A_0 = guess_1
@@ -270,16 +275,15 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
         double res = 0.;
         for (int guard = 0; guard < 17; guard++) {
           // ---- walk: a scalar integer chain (del is wave-uniform), no memory
+          // (branch-free: steps before `first` run on don't-care values and are overridden at j == first)
           int myd = 0, d = del;
 #pragma unroll
           for (int j = 1; j < 15; j++) {
-            if (j >= first) {
-              const int m = d & 3, q = d - m;
-              const int dn = __builtin_amdgcn_readlane(dv, 4 * j + m);
-              const int kk = __builtin_amdgcn_readlane(ks, 4 * j);
-              d = dn + (kk >= 0 ? (q << (kk & 31)) : (q >> ((-kk) & 31)));
-              if (lane == j + 1) myd = d;
-            }
+            d = (j == first) ? del : d;
+            const int m = d & 3, q = d - m;
+            const int dn = __builtin_amdgcn_readlane(dv, 4 * j + m);
+            d = dn + ((q << skl[j]) >> skr[j]);
+            if (lane == j + 1) myd = d;
           }
           if (lane > first && lane < 16) x = gBase + (double)myd * gU;
           STAMP(3);
@@ -724,7 +728,7 @@ __global__ __launch_bounds__(64) void k_mix(const MixJob *__restrict__ jobs, int
 __global__ __launch_bounds__(64) void k_cost(const CostJob *__restrict__ jobs, const int *__restrict__ pow2_bits) {
   __shared__ double cval[COST_BLK];
   __shared__ int32_t uval[COST_BLK];
-  __shared__ int32_t mint[COST_BLK];
+  __shared__ double smean[COST_BLK];
   __shared__ long long red[64];
   const CostJob job = jobs[blockIdx.x];
   const int lane = threadIdx.x, n = job.n;
@@ -744,16 +748,21 @@ __global__ __launch_bounds__(64) void k_cost(const CostJob *__restrict__ jobs, c
           cval[k] = (1. - 0.98) * val;  // RunExp::Update (utils.h:13-15)
         }
         __syncthreads();
-        if (lane == 0) {
-          for (int k = 0; k < cnt; k++) {
-            const int mi = (int)mean;
-            mint[k] = mi > 1 ? mi : 1;
-            mean = 0.98 * mean + cval[k];
+        if (lane == 0) {  // the RunExp recurrence alone: 2 dependent FP64 ops per sample
+          int k = 0;
+          for (; k + 8 <= cnt; k += 8) {
+            double cv[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) cv[u] = cval[k + u];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { smean[k + u] = mean; mean = 0.98 * mean + cv[u]; }
           }
+          for (; k < cnt; k++) { smean[k] = mean; mean = 0.98 * mean + cval[k]; }
         }
         __syncthreads();
         for (int k = lane; k < cnt; k += 64) {
-          const int m = mint[k];
+          const int mi = (int)smean[k];
+          const int m = mi > 1 ? mi : 1;
           nb += uval[k] / m + 1;
           if (m > 1) {  // ceil(log(m)/log(2)) with the host libm's value at exact powers of two
             const int fl = 31 - __clz(m);
