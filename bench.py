@@ -55,6 +55,24 @@ def cpu_baseline(seconds_budget=20.0):
             "sample": f"Optimize (84 candidates x {n // 8}-sample window) + full PredictStereoFrame of one {n}-sample high-profile frame, {dt:.1f} s on one core"}
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes of this same command
+    (profiles/*_pmc_hbm.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); None if not collected."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.json")))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            ks = json.load(f)["kernels"]
+        for name, v in ks.items():
+            if name.startswith("k_lms<1280"):
+                return v["hbm_bytes_per_dispatch"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -134,9 +152,11 @@ def main():
                                    "full optimizer population (84 GetCost per frame) + final full-frame predict (BASELINE configs[2])",
                        "frames_per_gpu": nfr, "candidates_per_frame": int(rows[0]), "parallelism": f"frames sharded x{world}, no collective"},
             "algorithmic_tflops_whole_path": cand_units * world * args.steps * FLOPS_UNIT_HIGH / dt / 1e12,
-            "roofline": {"bound": "fp64-valu (no MFMA GEMM; matrix pipe used as exact f64 adder)", "kernel": "k_lms<1280,640>",
+            "roofline": {"bound": "mfma", "kernel": "k_lms<1280,640>",
+                         "note": "FP64 compute bound (78.6 TFLOP/s vector = matrix FP64 peak); the real ceiling is the dependent-add "
+                                 "latency of the serial 1920-term sums, the matrix pipe is used as an exact f64 adder, not a GEMM",
                          "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_VECTOR_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / FP64_VECTOR_PEAK_TFLOPS, "traffic": pmc_traffic(),
                          "avg_launch_ms": 1e3 * avg_launch_s, "launches": lms_launches,
                          "units_per_launch": units_per_launch, "flops_per_unit": FLOPS_LMS1},
         }
