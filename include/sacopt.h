@@ -35,7 +35,10 @@ typedef struct {
 
 /* Residual outputs of PredictStereoFrame for one frame; any pointer may be NULL.
  * (FrameCoder::error / s2u_error / s2u_error_map and framestats[].maxbpn{,_map},
- *  src/codec.cpp:165-211.) Host or device pointers. */
+ *  src/codec.cpp:165-211.) Host or device pointers. When map0 or map1 is non-NULL the library
+ *  runs Remap::Analyse over the whole frame (as FrameCoder::Predict does, codec.cpp:448-452)
+ *  and Remap::Map per sample (src/coder/map.cpp:111-152) on the device; otherwise
+ *  maxbpn[2..3] are reported as -1. */
 typedef struct {
   int32_t *err0, *err1;     /* error[ch][0..n)          */
   int32_t *s2u0, *s2u1;     /* s2u_error[ch][0..n)      */

@@ -56,4 +56,17 @@ struct CostJob {
   int32_t n, nbuf;  // nbuf < 0: single-buffer mode, costs[0] = Calc(bufs[0])
 };
 
+// Remap (src/coder/map.cpp:89-152) for one (frame, channel).
+#define MAP_SCALE 32768
+#define MAP_TAB (2 * MAP_SCALE + 1)  // values -scale..scale
+struct MapJob {
+  const int32_t *s;   // whole frame (numsamples) -- Remap::Analyse input (codec.cpp:448-452)
+  const int32_t *sw;  // s + from: the predicted window
+  const int32_t *e;   // error[ch][0..n)
+  int32_t *m;         // out: s2u_error_map[ch][0..n) (may be NULL: only the max is wanted)
+  int32_t *tab;       // [MAP_TAB] scratch, zeroed before k_map_mark; after k_map_scan: tab[v+scale] = #used values in [-scale, v]
+  int32_t *mmax;      // [1] max of m (zeroed before the launch)
+  int32_t numsamples, n;
+};
+
 #endif

@@ -828,6 +828,64 @@ __global__ void k_rls(const double *pv, const double *val, int len, double alpha
 }
 
 // ------------------------------------------------------------------------------------------
+// Remap (src/coder/map.cpp:89-152): Analyse marks the sample values a frame uses; Map(pred,err)
+// counts the used values in (pred, pred+err] (err > 0) or [pred+err, pred) (err < 0). The count
+// is a rank difference on the used-value table, so: mark -> prefix sum -> O(1) per sample.
+// blockIdx.y = job (one per frame x channel).
+// ------------------------------------------------------------------------------------------
+__global__ void k_map_mark(const MapJob *jobs) {  // Remap::Analyse (map.cpp:111-130); tab zeroed beforehand
+  const MapJob job = jobs[blockIdx.y];
+  if (blockIdx.x == 0 && threadIdx.x == 0) job.tab[MAP_SCALE] = 1;  // isUsed(0) is always true (map.cpp:138)
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < job.numsamples; i += gridDim.x * blockDim.x) {
+    const int v = job.s[i];
+    if (v != 0 && v >= -MAP_SCALE && v <= MAP_SCALE) job.tab[v + MAP_SCALE] = 1;  // idempotent store; |v| > scale: "val too large", not marked
+  }
+}
+
+#define MAP_SCAN_NT 1024
+#define MAP_SCAN_PER ((MAP_TAB + MAP_SCAN_NT - 1) / MAP_SCAN_NT)
+__global__ void __launch_bounds__(MAP_SCAN_NT) k_map_scan(const MapJob *jobs) {  // in-place inclusive prefix sum of tab
+  __shared__ int part[MAP_SCAN_NT];
+  int32_t *tab = jobs[blockIdx.x].tab;
+  const int lo = threadIdx.x * MAP_SCAN_PER;
+  const int hi = lo + MAP_SCAN_PER < MAP_TAB ? lo + MAP_SCAN_PER : MAP_TAB;
+  int s = 0;
+  for (int i = lo; i < hi; i++) s += tab[i];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int d = 1; d < MAP_SCAN_NT; d <<= 1) {  // Hillis-Steele over the per-thread totals
+    const int v = (int)threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  int run = part[threadIdx.x] - s;
+  for (int i = lo; i < hi; i++) { run += tab[i]; tab[i] = run; }
+}
+
+__device__ __forceinline__ int map_rank(const int32_t *tab, int v) {  // #used values <= v
+  if (v < -MAP_SCALE) return 0;
+  return tab[(v > MAP_SCALE ? MAP_SCALE : v) + MAP_SCALE];
+}
+
+__global__ void k_map_apply(const MapJob *jobs) {  // Remap::Map + S2U + running max (codec.cpp:175-204)
+  const MapJob job = jobs[blockIdx.y];
+  int mx = 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < job.n; i += gridDim.x * blockDim.x) {
+    const int err = job.e[i];
+    const int pred = job.sw[i] - err;  // codec.cpp:175
+    int merr = 0;
+    if (err > 0) merr = map_rank(job.tab, pred + err) - map_rank(job.tab, pred);
+    else if (err < 0) merr = -(map_rank(job.tab, pred - 1) - map_rank(job.tab, pred + err - 1));
+    const int u = merr < 0 ? 2 * (-merr) : (merr > 0 ? 2 * merr - 1 : 0);  // MathUtils::S2U (utils.h:56-61)
+    if (job.m) job.m[i] = u;
+    mx = u > mx ? u : mx;
+  }
+  for (int o = 32; o; o >>= 1) { const int t = __shfl_xor(mx, o); mx = t > mx ? t : mx; }
+  if ((threadIdx.x & 63) == 0 && mx > 0) atomicMax(job.mmax, mx);
+}
+
+// ------------------------------------------------------------------------------------------
 // host-callable launchers (sacopt.cpp is compiled by the host compiler pass of the same TU set)
 // ------------------------------------------------------------------------------------------
 extern "C" int sacopt_lms_state_doubles(int S, int D) {  // 2 * R * NT of the matching k_lms instance
@@ -890,5 +948,14 @@ extern "C" int sacopt_launch_rls(int ns, const double *pv, const double *val, in
   if (ns == 4) hipLaunchKernelGGL((k_rls<4>), dim3(1), dim3(64), 0, st, pv, val, len, alpha, p);
   else if (ns == 3) hipLaunchKernelGGL((k_rls<3>), dim3(1), dim3(64), 0, st, pv, val, len, alpha, p);
   else return 1;
+  return hipGetLastError() != hipSuccess;
+}
+extern "C" int sacopt_launch_map(const MapJob *jobs, int njobs, int max_numsamples, int max_n, hipStream_t st) {
+  if (njobs <= 0) return 0;
+  int gb = (max_numsamples + 255) / 256; gb = gb < 1 ? 1 : (gb > 256 ? 256 : gb);
+  hipLaunchKernelGGL(k_map_mark, dim3(gb, njobs), dim3(256), 0, st, jobs);
+  hipLaunchKernelGGL(k_map_scan, dim3(njobs), dim3(MAP_SCAN_NT), 0, st, jobs);
+  gb = (max_n + 255) / 256; gb = gb < 1 ? 1 : (gb > 256 ? 256 : gb);
+  hipLaunchKernelGGL(k_map_apply, dim3(gb, njobs), dim3(256), 0, st, jobs);
   return hipGetLastError() != hipSuccess;
 }

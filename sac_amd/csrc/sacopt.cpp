@@ -28,6 +28,7 @@ int sacopt_launch_mix(int ns, const MixJob *jobs, int njobs, hipStream_t st);
 int sacopt_launch_cost(const CostJob *jobs, int njobs, const int *pow2_bits, hipStream_t st);
 int sacopt_launch_meanrms(const int32_t *e, int n, double *out, hipStream_t st);
 int sacopt_launch_rls(int ns, const double *pv, const double *val, int len, double alpha, double *p, hipStream_t st);
+int sacopt_launch_map(const MapJob *jobs, int njobs, int max_numsamples, int max_n, hipStream_t st);
 }
 
 static thread_local std::string g_create_error;
@@ -776,6 +777,71 @@ static int copy_out(sacopt_ctx *c, void *dst, const void *src_dev, size_t bytes)
 
 static int ilog2(int v) { int nb = 0; while (v >>= 1) nb++; return nb; }  // MathUtils::iLog2 (utils.h:42-46)
 
+// Residual outputs of a finished full pass (all work joined into c->st): error / s2u_error copies,
+// maxbpn, and -- when the caller asks for s2u_error_map -- Remap::Analyse over the whole frame
+// (codec.cpp:448-452) + Remap::Map per sample (codec.cpp:175-204) on the device. Ends the timed region.
+static size_t map_bytes(int n) { return 2 * ((((size_t)MAP_TAB * 4 + 255) & ~(size_t)255) + (((size_t)n * 4 + 255) & ~(size_t)255) + 256 + sizeof(MapJob)) + 1024; }
+static int emit_outputs(sacopt_ctx *c, const ProfDesc &pd, const std::vector<DevFrame> &fr, const std::vector<Chain> &chains,
+                        sacopt_residuals *out) {
+  const int nframes = (int)fr.size();
+  const int last = (pd.type == SACOPT_PROFILE_FAST) ? 0 : pd.nlms + 1;
+  std::vector<int32_t> um(2 * (size_t)nframes), mm(2 * (size_t)nframes, 0);
+  std::vector<MapJob> mj;
+  std::vector<int> mj_frame;
+  int max_ns = 0, max_n = 0;
+  for (int f = 0; f < nframes; f++) {
+    if (!out[f].map0 && !out[f].map1) continue;
+    const StageBuf &b = chains[f].sb[last];
+    for (int k = 0; k < 2; k++) {
+      MapJob j;
+      j.s = fr[f].s[k];
+      j.sw = fr[f].s[k] + fr[f].from;
+      j.e = b.e[k];
+      int32_t *dst = k ? out[f].map1 : out[f].map0;
+      j.m = (dst && is_device_ptr(dst)) ? dst : (dst ? arena_alloc<int32_t>(c, fr[f].n > 0 ? fr[f].n : 1) : nullptr);
+      j.tab = arena_alloc<int32_t>(c, MAP_TAB);
+      j.mmax = arena_alloc<int32_t>(c, 1);
+      if ((dst && !j.m) || !j.tab || !j.mmax) { c->err = "device arena exhausted"; return 1; }
+      HIPCK(c, hipMemsetAsync(j.tab, 0, (size_t)MAP_TAB * 4, c->st));
+      HIPCK(c, hipMemsetAsync(j.mmax, 0, 4, c->st));
+      j.numsamples = fr[f].numsamples;
+      j.n = fr[f].n;
+      mj.push_back(j);
+      mj_frame.push_back(f);
+    }
+    max_ns = fr[f].numsamples > max_ns ? fr[f].numsamples : max_ns;
+    max_n = fr[f].n > max_n ? fr[f].n : max_n;
+  }
+  if (!mj.empty()) {
+    MapJob *dj;
+    if (upload(c, mj, &dj)) return 1;
+    if (sacopt_launch_map(dj, (int)mj.size(), max_ns, max_n, c->st)) { c->err = "Remap launch failed"; return 1; }
+  }
+  for (size_t i = 0; i < mj.size(); i++) {
+    const int f = mj_frame[i], k = (int)(i & 1);
+    int32_t *dst = k ? out[f].map1 : out[f].map0;
+    if (dst && dst != mj[i].m && copy_out(c, dst, mj[i].m, (size_t)fr[f].n * 4)) return 1;
+    HIPCK(c, hipMemcpyAsync(&mm[2 * f + k], mj[i].mmax, 4, hipMemcpyDeviceToHost, c->st));
+  }
+  for (int f = 0; f < nframes; f++) {
+    const StageBuf &b = chains[f].sb[last];
+    const size_t bytes = (size_t)fr[f].n * 4;
+    if (copy_out(c, out[f].err0, b.e[0], bytes) || copy_out(c, out[f].err1, b.e[1], bytes) ||
+        copy_out(c, out[f].s2u0, b.u[0], bytes) || copy_out(c, out[f].s2u1, b.u[1], bytes))
+      return 1;
+    HIPCK(c, hipMemcpyAsync(&um[2 * f], b.umax, 8, hipMemcpyDeviceToHost, c->st));
+  }
+  if (end_timing(c)) return 1;
+  for (int f = 0; f < nframes; f++) {
+    out[f].maxbpn[0] = ilog2(um[2 * f]);  // codec.cpp:207-208
+    out[f].maxbpn[1] = ilog2(um[2 * f + 1]);
+    const bool maps = out[f].map0 || out[f].map1;
+    out[f].maxbpn[2] = maps ? ilog2(mm[2 * f]) : -1;  // codec.cpp:210-211 (only when map outputs are requested)
+    out[f].maxbpn[3] = maps ? ilog2(mm[2 * f + 1]) : -1;
+  }
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------ PredictStereoFrame
 extern "C" int sacopt_predict_stereo_frames(sacopt_ctx *c, int profile, int nframes, const sacopt_frame *frames,
                                             const int32_t *from, const int32_t *n, const double *coefs,
@@ -791,7 +857,8 @@ extern "C" int sacopt_predict_stereo_frames(sacopt_ctx *c, int profile, int nfra
   for (int f = 0; f < nframes; f++) {
     const int nn = n ? n[f] : frames[f].numsamples - (from ? from[f] : 0);
     need += chain_bytes(pd, nn > 0 ? nn : 0) + 2 * (((size_t)frames[f].numsamples * 4 + 255) & ~(size_t)255) + 4096 +
-            lpc_scratch_bytes(pd.type, nn > 0 ? nn : 0) + sizeof(LpcJob) + 256 + pipe_bytes(nn > 0 ? nn : 0);
+            lpc_scratch_bytes(pd.type, nn > 0 ? nn : 0) + sizeof(LpcJob) + 256 + pipe_bytes(nn > 0 ? nn : 0) +
+            ((out[f].map0 || out[f].map1) ? map_bytes(nn > 0 ? nn : 0) : 0);
   }
   if (arena_reserve(c, need)) return 1;
   HIPCK(c, hipEventRecord(c->ev0, c->st));
@@ -805,24 +872,7 @@ extern "C" int sacopt_predict_stereo_frames(sacopt_ctx *c, int profile, int nfra
   hipEvent_t done = nullptr;
   if (run_final_pass(c, pd, fr, chains, &done)) return 1;
   if (done) HIPCK(c, hipStreamWaitEvent(c->st, done, 0));
-  const int last = (pd.type == SACOPT_PROFILE_FAST) ? 0 : pd.nlms + 1;
-  std::vector<int32_t> um(2 * (size_t)nframes);
-  for (int f = 0; f < nframes; f++) {
-    const StageBuf &b = chains[f].sb[last];
-    const size_t bytes = (size_t)fr[f].n * 4;
-    if (copy_out(c, out[f].err0, b.e[0], bytes) || copy_out(c, out[f].err1, b.e[1], bytes) ||
-        copy_out(c, out[f].s2u0, b.u[0], bytes) || copy_out(c, out[f].s2u1, b.u[1], bytes))
-      return 1;
-    HIPCK(c, hipMemcpyAsync(&um[2 * f], b.umax, 8, hipMemcpyDeviceToHost, c->st));
-  }
-  if (end_timing(c)) return 1;
-  for (int f = 0; f < nframes; f++) {
-    out[f].maxbpn[0] = ilog2(um[2 * f]);      // codec.cpp:207-208
-    out[f].maxbpn[1] = ilog2(um[2 * f + 1]);
-    out[f].maxbpn[2] = out[f].maxbpn[3] = -1;  // Remap::Map outputs: not produced yet
-    if (out[f].map0 || out[f].map1) { c->err = "s2u_error_map outputs are not implemented yet"; return 1; }
-  }
-  return 0;
+  return emit_outputs(c, pd, fr, chains, out);
 }
 
 // ------------------------------------------------------------------------------------------ GetCost / Optimize
@@ -1034,7 +1084,8 @@ extern "C" int sacopt_encode_frames(sacopt_ctx *c, int profile, int nframes, con
   for (int f = 0; f < nframes; f++) {
     const int ns = frames[f].numsamples;
     if (ns < 0) { c->err = "negative numsamples"; return 1; }
-    need += chain_bytes(pd, ns) + 2 * (((size_t)ns * 4 + 255) & ~(size_t)255) + 4096 + lpc_scratch_bytes(pd.type, ns) + sizeof(LpcJob) + 256 + pipe_bytes(ns);
+    need += chain_bytes(pd, ns) + 2 * (((size_t)ns * 4 + 255) & ~(size_t)255) + 4096 + lpc_scratch_bytes(pd.type, ns) + sizeof(LpcJob) + 256 + pipe_bytes(ns) +
+            ((out[f].map0 || out[f].map1) ? map_bytes(ns) : 0);
     if (ncoef_loop > 0) need += optimize_bytes(pd, ncoef_loop, grid, total_cand, ns / 8);
   }
   if (arena_reserve(c, need)) return 1;
@@ -1055,24 +1106,7 @@ extern "C" int sacopt_encode_frames(sacopt_ctx *c, int profile, int nframes, con
     if (optimize_core(c, pd, win, prof, ncoef_loop, grid, best, nullptr, 0, nullptr)) return 1;
   }
   if (done) HIPCK(c, hipStreamWaitEvent(c->st, done, 0));
-  const int last = (pd.type == SACOPT_PROFILE_FAST) ? 0 : pd.nlms + 1;
-  std::vector<int32_t> um(2 * (size_t)nframes);
-  for (int f = 0; f < nframes; f++) {
-    const StageBuf &b = chains[f].sb[last];
-    const size_t bytes = (size_t)fr[f].n * 4;
-    if (copy_out(c, out[f].err0, b.e[0], bytes) || copy_out(c, out[f].err1, b.e[1], bytes) ||
-        copy_out(c, out[f].s2u0, b.u[0], bytes) || copy_out(c, out[f].s2u1, b.u[1], bytes))
-      return 1;
-    HIPCK(c, hipMemcpyAsync(&um[2 * f], b.umax, 8, hipMemcpyDeviceToHost, c->st));
-  }
-  if (end_timing(c)) return 1;
-  for (int f = 0; f < nframes; f++) {
-    out[f].maxbpn[0] = ilog2(um[2 * f]);
-    out[f].maxbpn[1] = ilog2(um[2 * f + 1]);
-    out[f].maxbpn[2] = out[f].maxbpn[3] = -1;
-    if (out[f].map0 || out[f].map1) { c->err = "s2u_error_map outputs are not implemented yet"; return 1; }
-  }
-  return 0;
+  return emit_outputs(c, pd, fr, chains, out);
 }
 
 // ------------------------------------------------------------------------------------------ cost on caller residuals

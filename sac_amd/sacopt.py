@@ -135,9 +135,26 @@ class Context:
             arr[i].numsamples = n
         return arr, keep
 
-    def predict(self, profile, frames, frm=None, n=None, coefs=None, device_out=None):
-        """Returns list of dicts (e0,e1,u0,u1,maxbpn) as numpy arrays; with device_out (list of dicts of
-        raw device pointers) the residuals are left on the device."""
+    @staticmethod
+    def _residuals(res, i, ni, device_out, maps):
+        if device_out is None:
+            keys = ("e0", "e1", "u0", "u1") + (("m0", "m1") if maps else ())
+            d = {k: np.zeros(max(ni, 0), np.int32) for k in keys}
+            res[i].err0, res[i].err1 = d["e0"].ctypes.data, d["e1"].ctypes.data
+            res[i].s2u0, res[i].s2u1 = d["u0"].ctypes.data, d["u1"].ctypes.data
+            if maps:
+                res[i].map0, res[i].map1 = d["m0"].ctypes.data, d["m1"].ctypes.data
+        else:
+            d = {}
+            res[i].err0, res[i].err1 = device_out[i].get("e0"), device_out[i].get("e1")
+            res[i].s2u0, res[i].s2u1 = device_out[i].get("u0"), device_out[i].get("u1")
+            res[i].map0, res[i].map1 = device_out[i].get("m0"), device_out[i].get("m1")
+        return d
+
+    def predict(self, profile, frames, frm=None, n=None, coefs=None, device_out=None, maps=False):
+        """Returns list of dicts (e0,e1,u0,u1[,m0,m1],maxbpn) as numpy arrays; with device_out (list of dicts
+        of raw device pointers) the residuals are left on the device. maps=True also asks for the
+        Remap::Map outputs (s2u_error_map, maxbpn_map)."""
         nf = len(frames)
         arr, keep = self._frames(frames)
         frm_a = None if frm is None else np.ascontiguousarray(frm, dtype=np.int32)
@@ -147,15 +164,7 @@ class Context:
         outs = []
         for i in range(nf):
             ni = int(n_a[i]) if n_a is not None else arr[i].numsamples - (int(frm_a[i]) if frm_a is not None else 0)
-            if device_out is None:
-                d = {k: np.zeros(max(ni, 0), np.int32) for k in ("e0", "e1", "u0", "u1")}
-                res[i].err0, res[i].err1 = d["e0"].ctypes.data, d["e1"].ctypes.data
-                res[i].s2u0, res[i].s2u1 = d["u0"].ctypes.data, d["u1"].ctypes.data
-            else:
-                d = {}
-                res[i].err0, res[i].err1 = device_out[i].get("e0"), device_out[i].get("e1")
-                res[i].s2u0, res[i].s2u1 = device_out[i].get("u0"), device_out[i].get("u1")
-            outs.append(d)
+            outs.append(self._residuals(res, i, ni, device_out, maps))
         self._ck(lib().sacopt_predict_stereo_frames(self._h, profile, nf, arr, _p(frm_a), _p(n_a), _p(cf), res))
         for i in range(nf):
             outs[i]["maxbpn"] = np.array(list(res[i].maxbpn), np.int32)
@@ -189,7 +198,7 @@ class Context:
                                               max_rows, _p(rows)))
         return best, [trace[f, :min(rows[f], max_rows)].copy() for f in range(nf)], rows
 
-    def encode(self, profile, frames, prof=None, ncoef_loop=None, device_out=None):
+    def encode(self, profile, frames, prof=None, ncoef_loop=None, device_out=None, maps=False):
         """FrameCoder::Predict with Optimize enabled: returns (best[nframes,ncoef], residual dicts)."""
         nf = len(frames)
         arr, keep = self._frames(frames)
@@ -201,15 +210,7 @@ class Context:
         res = (Residuals * max(nf, 1))()
         outs = []
         for i in range(nf):
-            if device_out is None:
-                d = {k: np.zeros(arr[i].numsamples, np.int32) for k in ("e0", "e1", "u0", "u1")}
-                res[i].err0, res[i].err1 = d["e0"].ctypes.data, d["e1"].ctypes.data
-                res[i].s2u0, res[i].s2u1 = d["u0"].ctypes.data, d["u1"].ctypes.data
-            else:
-                d = {}
-                res[i].err0, res[i].err1 = device_out[i].get("e0"), device_out[i].get("e1")
-                res[i].s2u0, res[i].s2u1 = device_out[i].get("u0"), device_out[i].get("u1")
-            outs.append(d)
+            outs.append(self._residuals(res, i, arr[i].numsamples, device_out, maps))
         self._ck(lib().sacopt_encode_frames(self._h, profile, nf, arr, _p(pf), ncoef_loop, _p(best), res))
         for i in range(nf):
             outs[i]["maxbpn"] = np.array(list(res[i].maxbpn), np.int32)

@@ -52,12 +52,15 @@ def test_cost_golden(ctx, golden):
 @pytest.mark.parametrize("prof", [0, 1, 2])
 def test_predict_golden(ctx, golden, prof):
     L, R = golden["pred_L"], golden["pred_R"]
-    out = ctx.predict(prof, [(L, R), (L, R)], frm=[0, 1500], n=[4096, 2000])
-    for key, tag in (("e0", "e0"), ("e1", "e1"), ("u0", "u0"), ("u1", "u1")):
-        assert np.array_equal(out[0][key], golden[f"pred{prof}_{tag}"]), key
-        assert np.array_equal(out[1][key], golden[f"predw{prof}_{tag}"]), key
-    assert np.array_equal(out[0]["maxbpn"][:2], golden[f"pred{prof}_maxbpn"][:2])
-    assert np.array_equal(out[1]["maxbpn"][:2], golden[f"predw{prof}_maxbpn"][:2])
+    out = ctx.predict(prof, [(L, R), (L, R)], frm=[0, 1500], n=[4096, 2000], maps=True)
+    for key in ("e0", "e1", "u0", "u1", "m0", "m1"):  # m* = s2u_error_map (Remap::Map on the device)
+        assert np.array_equal(out[0][key], golden[f"pred{prof}_{key}"]), key
+        assert np.array_equal(out[1][key], golden[f"predw{prof}_{key}"]), key
+    assert np.array_equal(out[0]["maxbpn"], golden[f"pred{prof}_maxbpn"])
+    assert np.array_equal(out[1]["maxbpn"], golden[f"predw{prof}_maxbpn"])
+    # without map outputs requested the map statistics are reported as -1
+    out = ctx.predict(prof, [(L, R)], frm=[0], n=[512])
+    assert list(out[0]["maxbpn"][2:]) == [-1, -1]
 
 
 def test_predict_custom_coefs_golden(ctx, golden):
@@ -79,12 +82,12 @@ def test_predict_pipelined_long_frames(ctx, oracle, prof):
     # frames longer than two pipeline chunks (2 x 22528) take the chunk-pipelined path with
     # carried stage state; ragged lengths make the last chunks differ per frame
     frames = [stereo_clip(50, 50000), stereo_clip(51, 46001)]
-    outs = ctx.predict(prof, frames)
+    outs = ctx.predict(prof, frames, maps=True)
     for (L, R), o in zip(frames, outs):
         ref = oracle.predict(prof, L, R, maps=True)
-        for k in ("e0", "e1", "u0", "u1"):
+        for k in ("e0", "e1", "u0", "u1", "m0", "m1"):
             assert np.array_equal(o[k], ref[k]), k
-        assert np.array_equal(o["maxbpn"][:2], ref["maxbpn"][:2])
+        assert np.array_equal(o["maxbpn"], ref["maxbpn"])
 
 
 def test_predict_edge_cases(ctx, oracle):
@@ -94,12 +97,20 @@ def test_predict_edge_cases(ctx, oracle):
     rs = np.random.RandomState(5)
     Lf = (np.sign(np.sin(np.arange(900) * 0.05)) * 30000 + rs.randint(-2000, 2000, 900)).astype(np.int32)
     Rf = (-Lf // 2 + rs.randint(-500, 500, 900)).astype(np.int32)
-    frames = [(L[:0], R[:0]), (L[:1], R[:1]), (L, R), (Z, Z), (Lf, Rf)]
+    # 17-bit-ish samples: values beyond Remap's +-32768 table ("val too large", map.cpp:116) and
+    # predictions outside it (isUsed -> false, map.cpp:134-135)
+    Lw = (Lf * 3).astype(np.int32); Rw = (Rf * 3).astype(np.int32)
+    frames = [(L[:0], R[:0]), (L[:1], R[:1]), (L, R), (Z, Z), (Lf, Rf), (Lw, Rw)]
     for prof in (0, 1, 2):
-        outs = ctx.predict(prof, frames)
+        outs = ctx.predict(prof, frames, maps=True)
         for (a, b), o in zip(frames, outs):
-            ref = oracle.predict(prof, a, b) if len(a) else dict(e0=a, e1=b)
-            assert np.array_equal(o["e0"], ref["e0"]) and np.array_equal(o["e1"], ref["e1"]), prof
+            if not len(a):
+                assert len(o["e0"]) == 0 and len(o["m0"]) == 0
+                continue
+            ref = oracle.predict(prof, a, b, maps=True)
+            for k in ("e0", "e1", "u0", "u1", "m0", "m1"):
+                assert np.array_equal(o[k], ref[k]), (prof, k)
+            assert np.array_equal(o["maxbpn"], ref["maxbpn"]), prof
 
 
 # ---------------------------------------------------------------- GetCost / Optimize

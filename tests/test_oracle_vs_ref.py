@@ -69,3 +69,16 @@ def test_silence(pair):
         a = o.predict(prof, Z, Z, maps=True); b = r.predict(prof, Z, Z, maps=True)
         for k in a:
             assert np.array_equal(a[k], b[k]), (prof, k)
+
+
+def test_samples_beyond_remap_table(pair):
+    # samples outside Remap's +-32768 table ("val too large", map.cpp:116,123: not marked) and
+    # predictions outside it (isUsed false, map.cpp:134-135)
+    o, r = pair
+    rs = np.random.RandomState(5)
+    L = (np.sign(np.sin(np.arange(900) * 0.05)) * 90000 + rs.randint(-6000, 6000, 900)).astype(np.int32)
+    R = (-L // 2 + rs.randint(-1500, 1500, 900)).astype(np.int32)
+    for prof in (0, 1, 2):
+        a = o.predict(prof, L, R, maps=True); b = r.predict(prof, L, R, maps=True)
+        for k in a:
+            assert np.array_equal(a[k], b[k]), (prof, k)
