@@ -54,6 +54,8 @@ struct CostJob {
   double *costs;               // nbuf/2 outputs: (Calc(ch0)+Calc(ch1))/2
   double *state;               // carried running mean (in/out), may be NULL
   int32_t n, nbuf;  // nbuf < 0: single-buffer mode, costs[0] = Calc(bufs[0])
+  double *scr;      // buffer-parallel form: [3*nbuf] guessed ends F, actual ends E, per-buffer costs (else NULL)
+  int32_t *ok;      // buffer-parallel form: [1] 1 = verified, the sequential kernel has nothing to do (else NULL)
 };
 
 // Remap (src/coder/map.cpp:89-152) for one (frame, channel).

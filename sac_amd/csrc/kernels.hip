@@ -135,13 +135,19 @@ template <int S, int D, int NT, int R, int RL, bool SPEC>
 __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, const float *__restrict__ gtab,
                                             int bits) {
   constexpr int T = S + D, T4 = T / 4, M = RL - 1, CH = LMS_CHUNK;
+  // SPEC: 16 segments of 120 products, padded to a stride of 122 doubles so that the 16 segment
+  // lanes of a ds_read_b64 half fall on 16 different 4-bank groups (stride 120 -> 4-way conflict)
+  constexpr int SEG = 120, SEGP = 122, TP = SPEC ? 16 * SEGP : T;
   static_assert(T % 4 == 0, "tap count must be a multiple of 4");
   static_assert(RL >= CH + (S > D ? S : D) + 1, "ring too short");
   static_assert(NT * R >= 2 * T, "not enough tap slots");
   static_assert(T4 % 16 == 0 || T4 <= 16, "unsupported tap count");
-  __shared__ double prods[2][T];
+  __shared__ double prods[2][TP];
   __shared__ double ring[2][RL];
   __shared__ double predv[2];
+  // predictions of the current chunk; written to HBM once per chunk by all threads (a store per
+  // sample would put an HBM write round trip in front of every barrier)
+  __shared__ double pbuf[2][CH];
   // speculative exact summation (SPEC): 16 segments x 4 candidate start values per channel
   __shared__ double sBase[2][17], sU[2][17], sInvU[2][17], sOut[2][16][4];
   __shared__ float tab[RSQ_LDS_MAX];
@@ -169,7 +175,7 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
     else { const int j = i - S; src = 1 - c; lag = (c == 0 ? 1 : 0) + j; mu[r] = job.mu2; }
     hsel[r] = src;
     hoff[r] = (-lag) & M;
-    paddr[r] = c * T + i;
+    paddr[r] = SPEC ? c * TP + (i / SEG) * SEGP + (i % SEG) : c * T + i;
     w[r] = 0.; eg[r] = 0.;
     if (!valid[r]) { hsel[r] = 0; hoff[r] = 0; paddr[r] = 0; }
     if (t0 > 0 && job.state) {  // resume: weights / gradient energies of the previous chunk
@@ -190,11 +196,23 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
   // Chains 0/1 are the two channels; chains 2..15 just repeat them (harmless, keeps loads unconditional).
   const double *mp = &prods[mc & 1][mk];
 
+  auto flush = [&](int tb, int te) {  // p[k] and val[k+1] = x - p (CalcError, profile.cpp:141-148) for times [tb, te)
+    for (int idx = tid; idx < 2 * CH; idx += NT) {
+      const int c = idx / CH, k = idx - c * CH, tau = tb + k;
+      if (tau < te) {
+        const double pv = pbuf[c][k];
+        double *po = c ? job.p[1] : job.p[0], *xo = c ? job.xn[1] : job.xn[0];
+        po[tau] = pv;
+        if (xo) xo[tau] = ring[c][tau & M] - pv;
+      }
+    }
+  };
   long long tmr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tq = 0;  // DEBUG phase timers (dbg & 128)
 #define STAMP(i) do { if (dbg & 128) { long long now_ = __builtin_amdgcn_s_memtime(); tmr[i] += now_ - tq; tq = now_; } } while (0)
   for (int t = t0; t < tend; t++) {
     if (dbg & 128) tq = __builtin_amdgcn_s_memtime();
     if ((t & (CH - 1)) == 0) {
+      if (t > t0) flush(t - CH, t);
       for (int idx = tid; idx < 2 * CH; idx += NT) {
         const int c = idx / CH, k = idx - c * CH, tau = t + k;
         const double *xs = c ? job.x[1] : job.x[0];
@@ -228,7 +246,7 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
       const int sc = wave & 1, sm = wave >> 1;
       const int jA = lane & 15, kA = lane >> 4, jD = 4 * ((lane >> 2) & 3) + (lane >> 4);
       const int dl = 16 * (lane & 3) + 4 * ((lane >> 2) & 3);  // D-layout lane of chain (lane & 15)
-      const uint32_t paddr = (uint32_t)(uintptr_t)&prods[sc][jA * 120 + kA];
+      const uint32_t paddr = (uint32_t)(uintptr_t)&prods[sc][jA * SEGP + kA];
       const int j16 = lane & 15;
       double gA = 0., gBase = 0., gU = 0., gIU = 0.;  // lanes 0..15 (and their mod-16 copies): per-boundary values
       if (sm == 0 && !(dbg & 64)) {  // P0: segment sums from zero -> guesses of the segment inputs
@@ -307,10 +325,7 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
         }
         if (lane == 60) {  // chain 15 lives in D lanes 60..63
           predv[sc] = res;
-          const double xc = ring[sc][t & M];
-          double *po = sc ? job.p[1] : job.p[0], *xo = sc ? job.xn[1] : job.xn[0];
-          po[t] = res;
-          if (xo) xo[t] = xc - res;  // CalcError (profile.cpp:141-148)
+          pbuf[sc][t & (CH - 1)] = res;
         }
       }
     } else
@@ -330,10 +345,7 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
       if (lane == 0 || lane == 16) {
         const int c = lane >> 4;
         predv[c] = acc;
-        const double xc = ring[c][t & M];
-        double *po = c ? job.p[1] : job.p[0], *xo = c ? job.xn[1] : job.xn[0];
-        po[t] = acc;
-        if (xo) xo[t] = xc - acc;  // CalcError (profile.cpp:141-148)
+        pbuf[c][t & (CH - 1)] = acc;
       }
     }
     __syncthreads();
@@ -352,7 +364,11 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
     }
     STAMP(7);
   }
-  if ((dbg & 128) && tid == 0) for (int i = 0; i < 8; i++) job.p[0][i] = (double)tmr[i];
+  if (tend > t0) flush((tend - 1) & ~(CH - 1), tend);
+  if (dbg & 128) {
+    __syncthreads();
+    if (tid == 0) for (int i = 0; i < 8; i++) job.p[0][i] = (double)tmr[i];
+  }
 #undef STAMP
   if (job.state) {
 #pragma unroll
@@ -360,6 +376,242 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
       job.state[r * NT + tid] = w[r];
       job.state[(R + r) * NT + tid] = eg[r];
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// LMSADA2(1280,640), one workgroup per (chain, CHANNEL). The two filters of a stereo pair only
+// read each other's *inputs* (profile.cpp:128-132), never each other's state, so they are
+// independent chains: blockIdx.x = 2*chain + channel. Compared with k_lms<..., SPEC> (both
+// channels in one workgroup) the tap update -- VALU-throughput bound -- has twice the SIMDs, and
+// the serial phases of one channel no longer wait for the other's verification retries.
+//
+// Per sample (3 barriers):
+//   products   w[i]*hist[i] -> LDS, 16 segments of 120, stride 122 (bank-conflict-free MFMA reads)
+//   P1         waves 0..3: every segment summed from +0 (one 30-step MFMA pass, 16 chains); the
+//              prefix of these sums = guessed segment inputs g_j; wave m then sums every segment
+//              EXACTLY from g_j + (m-2) ulp (second pass)
+//   walk       wave 0: the tables "input offset -> output offset" of the 15 boundaries are composed
+//              by doubling (3 rounds) and evaluated for all boundaries at once (4 rounds), instead
+//              of a 15-step serial walk
+//   P2         wave 0: every segment re-summed exactly from its walked input; each output must equal
+//              the next walked input bit for bit. By induction from x_0 = +0 the last output then
+//              IS the strict left-to-right sum (nlms.h:110-111). A mismatch pins the first wrong
+//              boundary to the exact value just computed and re-evaluates the later ones.
+//   update     nlms.h:114-129, all threads
+// Everything before P2 is a guess and only affects speed; exactness rests on P2 alone.
+// ------------------------------------------------------------------------------------------
+#define L1_NT 512
+#define L1_R 4
+#define L1_CH 256
+#define L1_RLO 2048
+#define L1_RLX 1024
+#define L1_SEG 120
+#define L1_SEGP 122
+
+// rsq_emul with the integer part folded (argument is eg + 0.001 > 0 or NaN):
+//   index  = bits [23-bits, 23] of the float (top mantissa bits + exponent parity)
+//   rescale: table value * 2^-q, q = ((e+1)>>1) - 64
+__device__ __forceinline__ double rsq_emul2(double a, const float *tab, int bits) {
+  const uint32_t u = __float_as_uint((float)a);
+  const uint32_t idx = (u >> (23 - bits)) & ((2u << bits) - 1u);
+  const uint32_t x = ((u + 0x800000u) >> 1) & 0x7f800000u;
+  uint32_t tb = __float_as_uint(tab[idx]) + (0x20000000u - x);
+  if ((u & 0x7f800000u) == 0x7f800000u) tb = (u & 0x7fffffu) ? (u | 0x400000u) : 0u;  // NaN stays NaN, +inf -> +0
+  return (double)__uint_as_float(tb);
+}
+
+__device__ __forceinline__ int ulp_shift(int v, int ea, int eb) {  // offset in ulps 2^ea -> ulps 2^eb (guess only)
+  int ks = (ea && eb) ? ea - eb : 0;
+  ks = ks > 31 ? 31 : (ks < -31 ? -31 : ks);
+  return ks >= 0 ? (int)((uint32_t)v << ks) : (v >> (-ks));
+}
+
+__global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs, const float *__restrict__ gtab, int bits) {
+  constexpr int S = 1280, T = 1920, NT = L1_NT, R = L1_R, CH = L1_CH, MO = L1_RLO - 1, MX = L1_RLX - 1;
+  constexpr int SEG = L1_SEG, SEGP = L1_SEGP;
+  __shared__ double prods[16 * SEGP];
+  __shared__ double ringo[L1_RLO];  // own channel's stage inputs   (taps 0..1279: lags 1..1280)
+  __shared__ double ringx[L1_RLX];  // other channel's stage inputs (taps 1280..1919)
+  __shared__ double pbuf[CH];
+  __shared__ double sOut[16][4];
+  __shared__ double predv;
+  __shared__ float tab[RSQ_LDS_MAX];
+
+  const LmsJob job = jobs[blockIdx.x >> 1];
+  const int c = blockIdx.x & 1;
+  const double *xo_in = c ? job.x[1] : job.x[0];
+  const double *xx_in = c ? job.x[0] : job.x[1];
+  double *pout = c ? job.p[1] : job.p[0];
+  double *xnout = c ? job.xn[1] : job.xn[0];
+  const int lagx = c ? 0 : 1;  // ch0: Predict(x1(t-1)); ch1: Predict(x0(t))  (profile.cpp:128-132)
+  const int tid = threadIdx.x, t0 = job.t0, tend = job.t0 + job.n;
+  const int dbg = bits >> 8;
+  bits &= 0xff;
+  for (int i = tid; i < (2 << bits); i += NT) tab[i] = gtab[i];
+  for (int i = tid; i < L1_RLO; i += NT) ringo[i] = 0.;
+  for (int i = tid; i < L1_RLX; i += NT) ringx[i] = 0.;
+  __syncthreads();
+
+  double w[R], eg[R], mu[R];
+  const double *hb[R];
+  int hoff[R], hmask[R], pa[R];
+  bool valid[R];
+  // carried state: same layout as k_lms<1280,640,...> (w at [tap], eg at [4096 + tap], tap = channel*1920 + i),
+  // so the two kernels may alternate between the chunks of one chain
+  double *st = job.state ? job.state + c * T : nullptr;
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    const int i = r * NT + tid;
+    valid[r] = i < T;
+    if (i < S) { hb[r] = ringo; hmask[r] = MO; hoff[r] = (-(1 + i)) & MO; mu[r] = job.mu1; }
+    else { hb[r] = ringx; hmask[r] = MX; hoff[r] = (-(lagx + (i - S))) & MX; mu[r] = job.mu2; }
+    pa[r] = (i / SEG) * SEGP + (i % SEG);
+    if (!valid[r]) { hb[r] = ringo; hmask[r] = MO; hoff[r] = 0; pa[r] = 0; }
+    w[r] = 0.; eg[r] = 0.;
+    if (t0 > 0 && st && valid[r]) { w[r] = st[i]; eg[r] = st[4096 + i]; }
+  }
+  if (t0 > 0) {  // history before the chunk comes straight from the stage's input arrays
+    for (int k = tid; k < L1_RLO - CH; k += NT) { const int tau = t0 - (L1_RLO - CH) + k; ringo[tau & MO] = tau >= 0 ? xo_in[tau] : 0.; }
+    for (int k = tid; k < L1_RLX - CH; k += NT) { const int tau = t0 - (L1_RLX - CH) + k; ringx[tau & MX] = tau >= 0 ? xx_in[tau] : 0.; }
+  }
+  const int lane = tid & 63, wave = tid >> 6;
+  const int jA = lane & 15, kA = lane >> 4;                      // A-operand lane: chain jA, term 4s+kA at step s
+  const int jD = 4 * ((lane >> 2) & 3) + (lane >> 4);             // chain held by this D-layout lane
+  const int dl = 16 * (lane & 3) + 4 * ((lane >> 2) & 3);         // D-layout lane of chain (lane & 15)
+  const int tj = lane >> 2, tm = lane & 3;                        // walk layout: boundary tj, input offset tm
+  const uint32_t paddr = (uint32_t)(uintptr_t)&prods[jA * SEGP + kA];
+  long long rounds = 0;
+
+  auto flush = [&](int tb, int te) {  // p and val[k+1] = x - p (CalcError, profile.cpp:141-148) for times [tb, te)
+    for (int k = tid; k < CH; k += NT) {
+      const int tau = tb + k;
+      if (tau < te) {
+        const double pv = pbuf[k];
+        pout[tau] = pv;
+        if (xnout) xnout[tau] = ringo[tau & MO] - pv;
+      }
+    }
+  };
+
+  for (int t = t0; t < tend; t++) {
+    if ((t & (CH - 1)) == 0) {
+      if (t > t0) flush(t - CH, t);
+      for (int k = tid; k < CH; k += NT) {
+        const int tau = t + k;
+        ringo[tau & MO] = (tau < tend) ? xo_in[tau] : 0.;
+        ringx[tau & MX] = (tau < tend) ? xx_in[tau] : 0.;
+      }
+      __syncthreads();
+    }
+    // ---- products w[i]*hist[i] (nlms.h:111)
+    double h[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      h[r] = hb[r][(t + hoff[r]) & hmask[r]];
+      if (valid[r]) prods[pa[r]] = w[r] * h[r];
+    }
+    __syncthreads();
+    // ---- P1: exact segment sums from the candidate inputs g_j + (m-2) ulp
+    double gBase = 0., gU = 0., gIU = 0.;  // lane l: boundary (l & 15)
+    if (wave < 4) {
+      // guess: every segment summed from +0 (exact for segment 0), prefix in any order
+      const double A = __shfl(mfma_pass30(paddr, 0.), dl);
+      double sh = A;
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) { const double v = __shfl_up(sh, o, 16); if (jA >= o) sh += v; }
+      sh -= A;
+      const double a0 = bcast(A, 0);
+      if (jA == 1) sh = a0;  // x_1 is known exactly
+      if (jA == 0) sh = 0.;
+      gU = ulp_pow2(sh, &gIU);
+      gBase = sh - 2. * gU;
+      const double stv = __shfl(gBase, jD) + (double)wave * __shfl(gU, jD);
+      const double o = mfma_pass30(paddr, stv);
+      if ((lane & 3) == 0) sOut[jD][wave] = o;
+    }
+    __syncthreads();
+    // ---- walk + P2 (wave 0)
+    if (wave == 0) {
+      const int ex = (__double2hiint(gU) >> 20) & 0x7ff;  // lane l: exponent field of the ulp at boundary l & 15 (0: no grid)
+      const double bB = __shfl(gBase, tj), bU = __shfl(gU, tj);
+      const int nb = tj < 15 ? tj + 1 : 15;
+      const double nB = __shfl(gBase, nb), nIU = __shfl(gIU, nb);
+      // J[k] at lane (tj, tm): offset at boundary tj + 2^k if the offset at boundary tj is tm
+      int J[4];
+      J[0] = (tj < 15) ? (int)((sOut[tj][tm] - nB) * nIU) : 0;
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const int p = (tj + (1 << k)) < 15 ? tj + (1 << k) : 15, tg = (tj + (2 << k)) < 15 ? tj + (2 << k) : 15;
+        const int ea = __shfl(ex, p), eb = __shfl(ex, tg);
+        const int dv = J[k], mm = dv & 3;
+        const int f = __shfl(J[k], 4 * p + mm);
+        J[k + 1] = f + ulp_shift(dv - mm, ea, eb);
+      }
+      double x = 0.;  // lane group tj: walked input of segment tj (x_0 = +0 exactly)
+      const double x1 = sOut[0][0];  // segment 0 summed from +0: exact
+      if (tj == 1) x = x1;
+      int sp = 1;                                         // boundaries <= sp are exact
+      int sd = __builtin_amdgcn_readlane(J[0], 0);        // offset of x_sp on boundary sp's grid
+      double res = 0.;
+      for (int guard = 0; guard < 17; guard++) {
+        // ---- evaluate the boundaries after sp: binary decomposition of the distance
+        const int n = tj - sp;
+        int p = sp, dv = sd;
+#pragma unroll
+        for (int k = 3; k >= 0; k--) {
+          const bool take = n > 0 && ((n >> k) & 1);
+          const int pn = (p + (1 << k)) < 15 ? p + (1 << k) : 15;
+          const int ea = __shfl(ex, p), eb = __shfl(ex, pn);
+          const int mm = dv & 3;
+          const int f = __shfl(J[k], 4 * p + mm);
+          const int dn = f + ulp_shift(dv - mm, ea, eb);
+          if (take) { dv = dn; p = pn; }
+        }
+        if (n > 0) x = bB + (double)dv * bU;
+        // ---- P2: verify every boundary
+        const double xs = __shfl(x, 4 * jD);
+        res = mfma_pass30(paddr, xs);
+        const double xn = __shfl(x, 4 * (jD < 15 ? jD + 1 : 15));
+        const bool bad = (jD < 15) && (__double_as_longlong(res) != __double_as_longlong(xn));
+        const unsigned long long mask = __ballot(bad);
+        rounds++;
+        if (mask == 0ull || (dbg & 16)) break;
+        int f = 0;  // first failing segment (D-layout lane of chain j: 16*(j&3) + 4*(j>>2))
+        while (f < 15 && !((mask >> (16 * (f & 3) + 4 * (f >> 2))) & 1ull)) f++;
+        f = __builtin_amdgcn_readfirstlane(f);
+        const double xt = bcast(res, 16 * (f & 3) + 4 * (f >> 2));  // exact x_{f+1}
+        if (tj == f + 1) x = xt;
+        sp = f + 1;
+        const double bq = bcast(gBase, f + 1), iq = bcast(gIU, f + 1);
+        sd = __builtin_amdgcn_readfirstlane((int)((xt - bq) * iq));
+      }
+      if (lane == 60) {  // chain 15 lives in D lanes 60..63
+        predv = res;
+        pbuf[t & (CH - 1)] = res;
+      }
+    }
+    __syncthreads();
+    // ---- Update (nlms.h:114-129)
+    const double err = ringo[t & MO] - predv;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      if (valid[r] && !(dbg & 2)) {
+        const double grad = err * h[r];
+        eg[r] = 0.95 * eg[r] + (1.0 - 0.95) * (grad * grad);
+        w[r] += (mu[r] * grad * rsq_emul2(eg[r] + 0.001, tab, bits));
+      }
+    }
+  }
+  if (tend > t0) flush((tend - 1) & ~(CH - 1), tend);
+  if (dbg & 128) {  // DEBUG: number of P2 passes
+    __syncthreads();
+    if (tid == 0) pout[t0] = (double)rounds;
+  }
+  if (st) {
+#pragma unroll
+    for (int r = 0; r < R; r++)
+      if (valid[r]) { st[r * NT + tid] = w[r]; st[4096 + r * NT + tid] = eg[r]; }
   }
 }
 
@@ -725,12 +977,63 @@ __global__ __launch_bounds__(64) void k_mix(const MixJob *__restrict__ jobs, int
 // any order, so it is accumulated in int64.
 // ------------------------------------------------------------------------------------------
 #define COST_BLK 512
+struct CostLds {
+  double cval[COST_BLK];
+  int32_t uval[COST_BLK];
+  double smean[COST_BLK];
+  long long red[64];
+};
+// One buffer: returns sum of bits (valid in lane 0), advances `mean` (lane 0). count_bits = false: recurrence only.
+__device__ __forceinline__ long long cost_buffer(const int32_t *e, int from, int n, double &mean, bool count_bits, int lane,
+                                                 const int *__restrict__ pow2_bits, CostLds &L) {
+  long long nb = 0;
+  for (int b0 = from; b0 < n; b0 += COST_BLK) {
+    const int cnt = min(COST_BLK, n - b0);
+    for (int k = lane; k < cnt; k += 64) {
+      const int32_t val = s2u(e[b0 + k]);
+      L.uval[k] = val;
+      L.cval[k] = (1. - 0.98) * val;  // RunExp::Update (utils.h:13-15)
+    }
+    __syncthreads();
+    if (lane == 0) {  // the RunExp recurrence alone: 2 dependent FP64 ops per sample
+      int k = 0;
+      for (; k + 8 <= cnt; k += 8) {
+        double cv[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) cv[u] = L.cval[k + u];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { L.smean[k + u] = mean; mean = 0.98 * mean + cv[u]; }
+      }
+      for (; k < cnt; k++) { L.smean[k] = mean; mean = 0.98 * mean + L.cval[k]; }
+    }
+    __syncthreads();
+    if (count_bits)
+      for (int k = lane; k < cnt; k += 64) {
+        const int mi = (int)L.smean[k];
+        const int m = mi > 1 ? mi : 1;
+        nb += L.uval[k] / m + 1;
+        if (m > 1) {  // ceil(log(m)/log(2)) with the host libm's value at exact powers of two
+          const int fl = 31 - __clz(m);
+          nb += ((m & (m - 1)) == 0) ? pow2_bits[fl] : fl + 1;
+        }
+      }
+    __syncthreads();
+  }
+  if (!count_bits) return 0;
+  L.red[lane] = nb;
+  __syncthreads();
+  long long tot = 0;
+  if (lane == 0) for (int i = 0; i < 64; i++) tot += L.red[i];
+  __syncthreads();
+  return tot;
+}
+
+// Sequential form: one wave per frame walks all buffers in call order. Also the fallback of the
+// buffer-parallel form below (returns at once when that one verified: *job.ok != 0).
 __global__ __launch_bounds__(64) void k_cost(const CostJob *__restrict__ jobs, const int *__restrict__ pow2_bits) {
-  __shared__ double cval[COST_BLK];
-  __shared__ int32_t uval[COST_BLK];
-  __shared__ double smean[COST_BLK];
-  __shared__ long long red[64];
+  __shared__ CostLds L;
   const CostJob job = jobs[blockIdx.x];
+  if (job.ok && *job.ok) return;
   const int lane = threadIdx.x, n = job.n;
   double mean = job.state ? *job.state : 0.;
   const bool single = job.nbuf < 0;
@@ -738,51 +1041,57 @@ __global__ __launch_bounds__(64) void k_cost(const CostJob *__restrict__ jobs, c
   for (int b = 0; b < nbuf; b += 2) {
     double c[2] = {0., 0.};
     for (int h = 0; h < (single ? 1 : 2); h++) {
-      const int32_t *e = job.bufs[b + h];
-      long long nb = 0;
-      for (int b0 = 0; b0 < n; b0 += COST_BLK) {
-        const int cnt = min(COST_BLK, n - b0);
-        for (int k = lane; k < cnt; k += 64) {
-          const int32_t val = s2u(e[b0 + k]);
-          uval[k] = val;
-          cval[k] = (1. - 0.98) * val;  // RunExp::Update (utils.h:13-15)
-        }
-        __syncthreads();
-        if (lane == 0) {  // the RunExp recurrence alone: 2 dependent FP64 ops per sample
-          int k = 0;
-          for (; k + 8 <= cnt; k += 8) {
-            double cv[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) cv[u] = cval[k + u];
-#pragma unroll
-            for (int u = 0; u < 8; u++) { smean[k + u] = mean; mean = 0.98 * mean + cv[u]; }
-          }
-          for (; k < cnt; k++) { smean[k] = mean; mean = 0.98 * mean + cval[k]; }
-        }
-        __syncthreads();
-        for (int k = lane; k < cnt; k += 64) {
-          const int mi = (int)smean[k];
-          const int m = mi > 1 ? mi : 1;
-          nb += uval[k] / m + 1;
-          if (m > 1) {  // ceil(log(m)/log(2)) with the host libm's value at exact powers of two
-            const int fl = 31 - __clz(m);
-            nb += ((m & (m - 1)) == 0) ? pow2_bits[fl] : fl + 1;
-          }
-        }
-        __syncthreads();
-      }
-      red[lane] = nb;
-      __syncthreads();
-      if (lane == 0) {
-        long long tot = 0;
-        for (int i = 0; i < 64; i++) tot += red[i];
-        c[h] = n ? (double)tot / (double)n : 0.;
-      }
-      __syncthreads();
+      const long long tot = cost_buffer(job.bufs[b + h], 0, n, mean, true, lane, pow2_bits, L);
+      c[h] = n ? (double)tot / (double)n : 0.;
     }
     if (lane == 0) job.costs[b >> 1] = single ? c[0] : (c[0] + c[1]) / 2.;  // GetCost (codec.cpp:349-351)
   }
   if (lane == 0 && job.state) *job.state = mean;
+}
+
+// Buffer-parallel form. The running mean forgets its start: after W samples the influence of the
+// initial value is 0.98^W (< 1e-35 for W = 4096) and, both trajectories being rounded onto the same
+// grid with the same inputs, they coalesce bit for bit. So: (tail) the mean after buffer b is
+// GUESSED by running the recurrence over the buffer's last W samples from 0; (par) every buffer is
+// costed in parallel from the guessed end of its predecessor; (fin) each buffer's actual end value
+// must EQUAL the guess its successor started from, bit for bit -- then, by induction from the
+// caller's initial state, every buffer saw exactly the state the sequential instance would have
+// given it. Any mismatch leaves *ok = 0 and the sequential kernel recomputes the frame.
+#define COST_WARM 4096
+__global__ __launch_bounds__(64) void k_cost_tail(const CostJob *__restrict__ jobs, const int *__restrict__ pow2_bits) {
+  __shared__ CostLds L;
+  const CostJob job = jobs[blockIdx.y];
+  const int b = blockIdx.x, n = job.n;
+  if (b >= job.nbuf - 1) return;
+  double mean = 0.;
+  const int from = n > COST_WARM ? ((n - COST_WARM) & ~7) : 0;
+  cost_buffer(job.bufs[b], from, n, mean, false, threadIdx.x, pow2_bits, L);
+  if (threadIdx.x == 0) job.scr[b] = mean;  // F[b]
+}
+__global__ __launch_bounds__(64) void k_cost_par(const CostJob *__restrict__ jobs, const int *__restrict__ pow2_bits) {
+  __shared__ CostLds L;
+  const CostJob job = jobs[blockIdx.y];
+  const int b = blockIdx.x, n = job.n, nbuf = job.nbuf;
+  if (b >= nbuf) return;
+  double mean = b ? job.scr[b - 1] : (job.state ? *job.state : 0.);
+  const long long tot = cost_buffer(job.bufs[b], 0, n, mean, true, threadIdx.x, pow2_bits, L);
+  if (threadIdx.x == 0) {
+    job.scr[nbuf + b] = mean;                                   // E[b]
+    job.scr[2 * nbuf + b] = n ? (double)tot / (double)n : 0.;   // Calc(buffer b)
+  }
+}
+__global__ void k_cost_fin(const CostJob *__restrict__ jobs, int njobs) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= njobs) return;
+  const CostJob job = jobs[f];
+  const int nbuf = job.nbuf;
+  bool ok = true;
+  for (int b = 0; b + 1 < nbuf; b++) ok = ok && (__double_as_longlong(job.scr[b]) == __double_as_longlong(job.scr[nbuf + b]));
+  if (ok) {
+    for (int b = 0; b < nbuf; b += 2) job.costs[b >> 1] = (job.scr[2 * nbuf + b] + job.scr[2 * nbuf + b + 1]) / 2.;  // GetCost (codec.cpp:349-351)
+    if (job.state) *job.state = job.scr[2 * nbuf - 1];
+  }
+  *job.ok = ok ? 1 : 0;
 }
 
 // single buffer variant used by sacopt_cost_golomb / meanrms
@@ -899,7 +1208,9 @@ extern "C" int sacopt_launch_lms(int S, int D, const LmsJob *jobs, int njobs, co
                                  hipStream_t st) {
   if (njobs <= 0) return 0;
   if (S == 1280 && D == 640) {
-    if ((bits >> 8) & 8) hipLaunchKernelGGL((k_lms<1280, 640, 1024, 4, 2048, false>), dim3(njobs), dim3(1024), 0, st, jobs, tab, bits);
+    // one workgroup per channel while that still leaves every workgroup a CU of its own
+    if (!((bits >> 8) & (8 | 256)) && (njobs <= 100 || ((bits >> 8) & 512))) hipLaunchKernelGGL(k_lms1c, dim3(2 * njobs), dim3(L1_NT), 0, st, jobs, tab, bits);
+    else if ((bits >> 8) & 8) hipLaunchKernelGGL((k_lms<1280, 640, 1024, 4, 2048, false>), dim3(njobs), dim3(1024), 0, st, jobs, tab, bits);
     else hipLaunchKernelGGL((k_lms<1280, 640, 512, 8, 2048, true>), dim3(njobs), dim3(512), 0, st, jobs, tab, bits);
   }
   else if (S == 256 && D == 128) hipLaunchKernelGGL((k_lms<256, 128, 256, 3, 1024, false>), dim3(njobs), dim3(256), 0, st, jobs, tab, bits);
@@ -936,6 +1247,16 @@ extern "C" int sacopt_launch_mix(int ns, const MixJob *jobs, int njobs, hipStrea
 }
 extern "C" int sacopt_launch_cost(const CostJob *jobs, int njobs, const int *pow2_bits, hipStream_t st) {
   if (njobs <= 0) return 0;
+  hipLaunchKernelGGL(k_cost, dim3(njobs), dim3(64), 0, st, jobs, pow2_bits);
+  return hipGetLastError() != hipSuccess;
+}
+// Buffer-parallel CostGolomb over nbuf (> 0, even) buffers per frame; jobs[].scr / ok must be set.
+// Always followed by the sequential kernel, which returns immediately for verified frames.
+extern "C" int sacopt_launch_cost_par(const CostJob *jobs, int njobs, int nbuf, const int *pow2_bits, hipStream_t st) {
+  if (njobs <= 0) return 0;
+  hipLaunchKernelGGL(k_cost_tail, dim3(nbuf, njobs), dim3(64), 0, st, jobs, pow2_bits);
+  hipLaunchKernelGGL(k_cost_par, dim3(nbuf, njobs), dim3(64), 0, st, jobs, pow2_bits);
+  hipLaunchKernelGGL(k_cost_fin, dim3((njobs + 63) / 64), dim3(64), 0, st, jobs, njobs);
   hipLaunchKernelGGL(k_cost, dim3(njobs), dim3(64), 0, st, jobs, pow2_bits);
   return hipGetLastError() != hipSuccess;
 }

@@ -26,6 +26,7 @@ int sacopt_launch_lpc3(const LpcJob *jobs, int njobs, int max_n, hipStream_t st)
 int sacopt_launch_lpc2(const LpcJob *jobs, int njobs, int max_n, hipStream_t st);
 int sacopt_launch_mix(int ns, const MixJob *jobs, int njobs, hipStream_t st);
 int sacopt_launch_cost(const CostJob *jobs, int njobs, const int *pow2_bits, hipStream_t st);
+int sacopt_launch_cost_par(const CostJob *jobs, int njobs, int nbuf, const int *pow2_bits, hipStream_t st);
 int sacopt_launch_meanrms(const int32_t *e, int n, double *out, hipStream_t st);
 int sacopt_launch_rls(int ns, const double *pv, const double *val, int len, double alpha, double *p, hipStream_t st);
 int sacopt_launch_map(const MapJob *jobs, int njobs, int max_numsamples, int max_n, hipStream_t st);
@@ -198,6 +199,7 @@ extern "C" int sacopt_create(int device, const float *rsqrt_tab, int rsqrt_bits,
   sacopt_ctx *c = new sacopt_ctx;
   c->device = device;
   c->bits = bits;
+  if (const char *dbg = getenv("SACOPT_DBG_ALL")) c->bits |= atoi(dbg) << 8;  // kernel-variant switches for A/B timing (kernels.hip)
   auto fail = [&](const char *what) { g_create_error = what; delete c; return 1; };
   if (hipSetDevice(device) != hipSuccess) return fail("hipSetDevice failed");
   if (hipStreamCreate(&c->st) != hipSuccess || hipStreamCreate(&c->sA) != hipSuccess || hipStreamCreate(&c->sB) != hipSuccess)
@@ -899,10 +901,13 @@ static int cost_round(sacopt_ctx *c, const ProfDesc &pd, const std::vector<DevFr
     jobs[f].state = d_state + f;
     jobs[f].n = fr[f].n;
     jobs[f].nbuf = 2 * ncand;
+    jobs[f].scr = arena_alloc<double>(c, 6 * (size_t)ncand);
+    jobs[f].ok = arena_alloc<int32_t>(c, 1);
+    if (!jobs[f].scr || !jobs[f].ok) { c->err = "device arena exhausted"; return 1; }
   }
   CostJob *dj;
   if (upload(c, jobs, &dj)) return 1;
-  if (sacopt_launch_cost(dj, nframes, c->d_pow2, c->st)) { c->err = "k_cost launch failed"; return 1; }
+  if (sacopt_launch_cost_par(dj, nframes, 2 * ncand, c->d_pow2, c->st)) { c->err = "k_cost launch failed"; return 1; }
   costs_host.resize((size_t)nframes * ncand);
   HIPCK(c, hipMemcpyAsync(costs_host.data(), d_costs, costs_host.size() * 8, hipMemcpyDeviceToHost, c->st));
   HIPCK(c, hipStreamSynchronize(c->st));
@@ -968,7 +973,8 @@ static size_t optimize_bytes(const ProfDesc &pd, int ncoef_loop, const std::vect
   size_t lpc_jobs = 1;  // most LPC jobs of this frame alive in one round
   for (int i = 0; i < ncoef_loop; i++)
     if (pd.nprefix[0] > i && grid[i].size() > lpc_jobs) lpc_jobs = grid[i].size();
-  return total_cand * (chain_bytes(pd, wn) + 256 + sizeof(LpcJob)) + 8192 + lpc_jobs * (lpc_scratch_bytes(pd.type, wn) + 256);
+  lpc_jobs += 1;  // the baseline chain rides along with the first round
+  return total_cand * (chain_bytes(pd, wn) + 1024 + sizeof(LpcJob)) + 32768 + lpc_jobs * (lpc_scratch_bytes(pd.type, wn) + 256);
 }
 
 // The search itself, on frames already staged (fr[f].from/n = optimisation window), all on c->st.
@@ -991,37 +997,38 @@ static int optimize_core(sacopt_ctx *c, const ProfDesc &pd, const std::vector<De
     }
     rows[f]++;
   };
-  {  // baseline: GetCost(profile, &CostFunc, 0, coefs[0].vdef, ...) (codec.cpp:386)
-    std::vector<Chain> chains(nframes);
-    for (int f = 0; f < nframes; f++) { chains[f].frame = f; memcpy(chains[f].coefs, cur[f].data(), 8 * pd.ncoef); }
-    if (eval_chains(c, pd, fr, chains, memo)) return 1;
-    std::vector<double> costs;
-    if (cost_round(c, pd, fr, chains, 1, d_state, costs)) return 1;
-    for (int f = 0; f < nframes; f++) { best_cost[f] = costs[f]; add_row(f, -1, cur[f][0], costs[f]); }
-  }
-  for (int i = 0; i < ncoef_loop; i++) {
-    const int nc = (int)grid[i].size();
-    if (!nc) continue;
-    std::vector<Chain> chains((size_t)nframes * nc);
+  // The baseline call GetCost(profile, &CostFunc, 0, coefs[0].vdef, ...) (codec.cpp:386) does not depend on
+  // anything the search decides, so it is evaluated together with the first round's candidates
+  // (first in CostGolomb call order, exactly where the reference makes it).
+  bool base_done = false;
+  for (int i = 0; i <= ncoef_loop; i++) {
+    const int nc = i < ncoef_loop ? (int)grid[i].size() : 0;
+    if (i < ncoef_loop && !nc) continue;
+    if (i == ncoef_loop && base_done) break;  // i == ncoef_loop: no round at all -> baseline alone
+    const int nb = base_done ? 0 : 1, tot = nc + nb;
+    std::vector<Chain> chains((size_t)nframes * tot);
     for (int f = 0; f < nframes; f++)
-      for (int k = 0; k < nc; k++) {
-        Chain &ch = chains[(size_t)f * nc + k];
+      for (int k = 0; k < tot; k++) {
+        Chain &ch = chains[(size_t)f * tot + k];
         ch.frame = f;
         memcpy(ch.coefs, cur[f].data(), 8 * pd.ncoef);
-        ch.coefs[i] = grid[i][k];
+        if (k >= nb) ch.coefs[i] = grid[i][k - nb];
       }
     if (eval_chains(c, pd, fr, chains, memo)) return 1;
     std::vector<double> costs;
-    if (cost_round(c, pd, fr, chains, nc, d_state, costs)) return 1;
+    if (cost_round(c, pd, fr, chains, tot, d_state, costs)) return 1;
     for (int f = 0; f < nframes; f++) {
+      if (nb) { best_cost[f] = costs[(size_t)f * tot]; add_row(f, -1, cur[f][0], best_cost[f]); }
+      if (!nc) continue;
       double best_x = cur[f][i];
       for (int k = 0; k < nc; k++) {
-        const double cost = costs[(size_t)f * nc + k];
+        const double cost = costs[(size_t)f * tot + nb + k];
         add_row(f, i, grid[i][k], cost);
         if (cost < best_cost[f]) { best_x = grid[i][k]; best_cost[f] = cost; }  // strict <: earliest wins ties (codec.cpp:399)
       }
       cur[f][i] = best_x;  // later coefficients see earlier winners (codec.cpp:406)
     }
+    base_done = true;
   }
   for (int f = 0; f < nframes; f++) {
     memcpy(best + (size_t)f * pd.ncoef, cur[f].data(), 8 * pd.ncoef);
@@ -1132,7 +1139,7 @@ extern "C" int sacopt_cost_golomb(sacopt_ctx *c, const int32_t *buf, int n, doub
   if (upload(c, stv, &d_state)) return 1;
   double *d_cost = arena_alloc<double>(c, 2);
   CostJob j;
-  j.bufs = d_bufs; j.costs = d_cost; j.state = d_state; j.n = n; j.nbuf = -1;  // nbuf < 0: single-buffer mode
+  j.bufs = d_bufs; j.costs = d_cost; j.state = d_state; j.n = n; j.nbuf = -1; j.scr = nullptr; j.ok = nullptr;  // nbuf < 0: single-buffer mode
   std::vector<CostJob> jobs = {j};
   CostJob *dj;
   if (upload(c, jobs, &dj)) return 1;
