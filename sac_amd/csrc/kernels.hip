@@ -876,14 +876,36 @@ __global__ __launch_bounds__(256) void k_pred2(const LpcJob *__restrict__ jobs) 
 // ------------------------------------------------------------------------------------------
 // Stage mixer + residual: RLS(NS, alpha) (src/pred/rls.cpp:61-108) over the cumulative stage sums
 // (profile.cpp:134), prediction rounding and residual (profile.cpp:152-157), S2U and max
-// (codec.cpp:188-211). The two channels' mixers are independent: one lane per (chain, channel).
+// (codec.cpp:188-211). The two channels' mixers are independent: one UNIT per (chain, channel).
+//
+// A wave issues one FP64 instruction every ~14 cycles whether or not it depends on the previous
+// one, so the ~260 scalar operations of one RLS step are spread over 16 lanes: lane (i, j) of a
+// unit owns P[i][j]; row sums come from quad broadcasts (DPP), the column / vector gathers from
+// cross-lane reads. Every scalar is still produced by the reference's operation sequence (each
+// sum starts at 0. and adds its terms in index order). 4 units per wave.
 // ------------------------------------------------------------------------------------------
+template <int JJ>
+__device__ __forceinline__ double quad_bcast(double v) {  // value of lane JJ of this lane's quad
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_mov_dpp(lo, JJ * 0x55, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_mov_dpp(hi, JJ * 0x55, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+template <int NS>
+__device__ __forceinline__ double pick(const double (&a)[NS], int k) {  // a[k] for a register array (0. out of range)
+  double r = 0.;
+#pragma unroll
+  for (int q = 0; q < NS; q++) r = (k == q) ? a[q] : r;
+  return r;
+}
+
 template <int NS>
 __global__ __launch_bounds__(64) void k_mix(const MixJob *__restrict__ jobs, int njobs) {
-  const int gid = blockIdx.x * 64 + threadIdx.x;
-  if (gid >= 2 * njobs) return;
-  const MixJob &job = jobs[gid >> 1];
-  const int ch = gid & 1, t0 = job.t0, tend = job.t0 + job.n;
+  const int lane = threadIdx.x, i = (lane >> 2) & 3, j = lane & 3, base16 = lane & ~15;
+  const int unit = blockIdx.x * 4 + (lane >> 4);
+  const bool live = unit < 2 * njobs;
+  const MixJob &job = jobs[live ? (unit >> 1) : 0];
+  const int ch = unit & 1, t0 = job.t0, n = live ? job.n : 0;
   const double alpha = job.alpha;
   const int32_t *s = job.s[ch];
   const double *p0 = job.p0[ch], *x1 = job.x1[ch];
@@ -891,81 +913,96 @@ __global__ __launch_bounds__(64) void k_mix(const MixJob *__restrict__ jobs, int
 #pragma unroll
   for (int k = 0; k < NS; k++) pk[k] = job.pk[k][ch];
   int32_t *eo = job.e[ch], *uo = job.u[ch];
-  double w[NS], P[NS][NS];
+  const bool inm = i < NS && j < NS, writer = (lane & 15) == 0;
+  double w[NS], P = (inm && i == j) ? 1. : 0.;
 #pragma unroll
-  for (int i = 0; i < NS; i++) {
-    w[i] = 0.;
-#pragma unroll
-    for (int j = 0; j < NS; j++) P[i][j] = (i == j) ? 1. : 0.;
-  }
+  for (int k = 0; k < NS; k++) w[k] = 0.;
   int32_t umax = 0;
   double *stp = job.state ? job.state + ch * MIX_STATE : nullptr;
-  if (t0 > 0 && stp) {
+  if (live && t0 > 0 && stp) {
 #pragma unroll
-    for (int i = 0; i < NS; i++) {
-      w[i] = stp[i];
-#pragma unroll
-      for (int j = 0; j < NS; j++) P[i][j] = stp[4 + i * NS + j];
-    }
+    for (int k = 0; k < NS; k++) w[k] = stp[k];
+    if (inm) P = stp[4 + i * NS + j];
     umax = (int32_t)stp[20];
   }
-  for (int t = t0; t < tend; t++) {
-    double hist[NS];
-    hist[0] = pk[0][t];
+  int nmax = n;  // wave-uniform trip count: the longest of the 4 units
+  nmax = max(nmax, __shfl_xor(nmax, 16));
+  nmax = max(nmax, __shfl_xor(nmax, 32));
+  const double ia = 1. / alpha;
+  // inputs of the next step are fetched one step ahead
+  double npk[NS], np0 = 0., nx1 = 0.;
+  int32_t ns = 0;
 #pragma unroll
-    for (int k = 1; k < NS; k++) hist[k] = hist[k - 1] + pk[k][t];  // pv (profile.cpp:134)
-    double p = 0.;
+  for (int k = 0; k < NS; k++) npk[k] = 0.;
+  if (n > 0) {
 #pragma unroll
-    for (int i = 0; i < NS; i++) p += hist[i] * w[i];  // RLS::Predict (rls.cpp:67-72)
-    const int32_t v = s[t];
-    const int32_t q = (int32_t)round(p0[t] + p);
-    const int32_t e = v - q;
-    if (eo) eo[t] = e;
-    const int32_t ue = s2u(e);
-    if (uo) uo[t] = ue;
-    umax = ue > umax ? ue : umax;
-    // RLS::Update(val[ch][1]) (rls.cpp:80-108)
-    double vt1[NS], kk[NS], m2[NS][NS];
-#pragma unroll
-    for (int i = 0; i < NS; i++) {
-      double sum = 0.;
-#pragma unroll
-      for (int j = 0; j < NS; j++) sum += P[i][j] * hist[j];
-      vt1[i] = sum;
-    }
-    double inner = 0.;
-#pragma unroll
-    for (int i = 0; i < NS; i++) inner += hist[i] * vt1[i];
-    const double sc = 1. / (alpha + inner);
-#pragma unroll
-    for (int i = 0; i < NS; i++) kk[i] = sc * vt1[i];
-#pragma unroll
-    for (int i = 0; i < NS; i++)
-#pragma unroll
-      for (int j = 0; j < NS; j++) {
-        double sum = 0.;
-#pragma unroll
-        for (int k = 0; k < NS; k++) sum += (kk[i] * hist[k]) * P[k][j];
-        m2[i][j] = sum;
-      }
-    const double ia = 1. / alpha;
-#pragma unroll
-    for (int i = 0; i < NS; i++)
-#pragma unroll
-      for (int j = 0; j < NS; j++) P[i][j] = ia * (P[i][j] - m2[i][j]);
-    const double dv = x1[t] - p;
-#pragma unroll
-    for (int i = 0; i < NS; i++) w[i] = w[i] + dv * kk[i];
+    for (int k = 0; k < NS; k++) npk[k] = pk[k][t0];
+    np0 = p0[t0]; nx1 = x1[t0]; ns = s[t0];
   }
-  if (job.umax) job.umax[ch] = umax;
-  if (stp) {
+  for (int it = 0; it < nmax; it++) {
+    if (it < n) {
+      const int t = t0 + it;
+      double h[NS];
+      h[0] = npk[0];
 #pragma unroll
-    for (int i = 0; i < NS; i++) {
-      stp[i] = w[i];
+      for (int k = 1; k < NS; k++) h[k] = h[k - 1] + npk[k];  // pv (profile.cpp:134)
+      const double cp0 = np0, cx1 = nx1;
+      const int32_t v = ns;
+      if (it + 1 < n) {
 #pragma unroll
-      for (int j = 0; j < NS; j++) stp[4 + i * NS + j] = P[i][j];
+        for (int k = 0; k < NS; k++) npk[k] = pk[k][t + 1];
+        np0 = p0[t + 1]; nx1 = x1[t + 1]; ns = s[t + 1];
+      }
+      double pc[NS];  // column j of P (before the update): P[k][j]
+#pragma unroll
+      for (int k = 0; k < NS; k++) pc[k] = __shfl(P, base16 + 4 * k + j);
+      double p = 0.;
+#pragma unroll
+      for (int k = 0; k < NS; k++) p += h[k] * w[k];  // RLS::Predict (rls.cpp:67-72)
+      const int32_t q = (int32_t)round(cp0 + p);
+      const int32_t e = v - q;
+      const int32_t ue = s2u(e);
+      if (writer) {
+        if (eo) eo[t] = e;
+        if (uo) uo[t] = ue;
+      }
+      umax = ue > umax ? ue : umax;
+      // RLS::Update(val[ch][1]) (rls.cpp:80-108)
+      const double pr = P * pick<NS>(h, j);  // P[i][j]*hist[j]
+      double vt = 0.;                        // vt1[i] = sum_j P[i][j]*hist[j]
+      vt += quad_bcast<0>(pr);
+      vt += quad_bcast<1>(pr);
+      vt += quad_bcast<2>(pr);
+      if (NS > 3) vt += quad_bcast<3>(pr);
+      double v1[NS];
+#pragma unroll
+      for (int k = 0; k < NS; k++) v1[k] = __shfl(vt, base16 + 4 * k);
+      double inner = 0.;
+#pragma unroll
+      for (int k = 0; k < NS; k++) inner += h[k] * v1[k];
+      const double sc = 1. / (alpha + inner);
+      double kk[NS];
+#pragma unroll
+      for (int k = 0; k < NS; k++) kk[k] = sc * v1[k];
+      const double ki = pick<NS>(kk, i);
+      double m2 = 0.;  // m2[i][j] = sum_k (k[i]*hist[k])*P[k][j]
+#pragma unroll
+      for (int k = 0; k < NS; k++) m2 += (ki * h[k]) * pc[k];
+      P = ia * (P - m2);
+      const double dv = cx1 - p;
+#pragma unroll
+      for (int k = 0; k < NS; k++) w[k] = w[k] + dv * kk[k];
     }
-    stp[20] = (double)umax;
+  }
+  if (!live) return;
+  if (writer && job.umax) job.umax[ch] = umax;
+  if (stp) {
+    if (writer) {
+#pragma unroll
+      for (int k = 0; k < NS; k++) stp[k] = w[k];
+      stp[20] = (double)umax;
+    }
+    if (inm) stp[4 + i * NS + j] = P;
   }
 }
 
@@ -1239,8 +1276,8 @@ extern "C" int sacopt_launch_lpc2(const LpcJob *jobs, int njobs, int max_n, hipS
 }
 extern "C" int sacopt_launch_mix(int ns, const MixJob *jobs, int njobs, hipStream_t st) {
   if (njobs <= 0) return 0;
-  const int blocks = (2 * njobs + 63) / 64;
-  if (ns == 4) hipLaunchKernelGGL((k_mix<4>), dim3(blocks), dim3(64), 0, st, jobs, njobs);
+  const int blocks = (2 * njobs + 3) / 4;
+  if (ns == 4) hipLaunchKernelGGL((k_mix<4>), dim3(blocks), dim3(64), 0, st, jobs, njobs);  // 4 units per wave
   else if (ns == 3) hipLaunchKernelGGL((k_mix<3>), dim3(blocks), dim3(64), 0, st, jobs, njobs);
   else return 1;
   return hipGetLastError() != hipSuccess;
