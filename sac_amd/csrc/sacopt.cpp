@@ -39,6 +39,7 @@ struct sacopt_ctx {
   hipStream_t st = nullptr;
   hipStream_t sA = nullptr, sB = nullptr;  // final-pass pipeline: dominant LMS stage / everything else
   hipStream_t sC = nullptr;                // follower stages of the optimizer rounds
+  hipStream_t sD = nullptr;                // final-pass pipeline: stages behind the second LMS stage (may be NULL)
   std::vector<hipEvent_t> pipe_ev;         // events of the last call's pipeline
   float *d_tab = nullptr;
   int bits = 0;
@@ -211,6 +212,13 @@ extern "C" int sacopt_create(int device, const float *rsqrt_tab, int rsqrt_bits,
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
     if (hipStreamCreateWithPriority(&c->sC, hipStreamDefault, hi) != hipSuccess) return fail("hipStreamCreateWithPriority failed");
+    // A stream with an explicit CU mask gets a hardware queue of its own (queues are only shared between
+    // streams with the same mask); the mask itself is left full.
+    if (!getenv("SACOPT_NO_SD")) {
+      uint32_t mask[8];
+      for (int k = 0; k < 8; k++) mask[k] = 0xffffffffu;
+      if (hipExtStreamCreateWithCUMask(&c->sD, 8, mask) != hipSuccess) { (void)hipGetLastError(); c->sD = nullptr; }
+    }
   }
   if (hipMalloc(&c->d_tab, sizeof(float) * (2 << bits)) != hipSuccess) return fail("hipMalloc(table) failed");
   if (hipMemcpy(c->d_tab, tab.data(), sizeof(float) * (2 << bits), hipMemcpyHostToDevice) != hipSuccess) return fail("table upload failed");
@@ -238,6 +246,7 @@ extern "C" void sacopt_destroy(sacopt_ctx *c) {
   if (c->sA) (void)hipStreamDestroy(c->sA);
   if (c->sB) (void)hipStreamDestroy(c->sB);
   if (c->sC) (void)hipStreamDestroy(c->sC);
+  if (c->sD) (void)hipStreamDestroy(c->sD);
   if (c->st) (void)hipStreamDestroy(c->st);
   delete c;
 }
@@ -368,9 +377,12 @@ static int lpc_scratch_alloc(sacopt_ctx *c, int type, LpcJob &j) {
   return 0;
 }
 
+// Chunk of the full-frame pipeline (final_pass_enqueue): short enough that the follower stages of the last
+// chunk are a small tail, long enough that kernel prologues (table + history reload) stay negligible.
+#define PIPE_CHUNK (16 * LMS_CHUNK) /* 8192 samples */
 // job tables + carried state of the pipelined pass for one chain of n samples
 static size_t pipe_bytes(int n) {
-  const size_t nchunk = (size_t)n / (44 * LMS_CHUNK) + 1;
+  const size_t nchunk = (size_t)n / PIPE_CHUNK + 1;
   return nchunk * (4 * (sizeof(LmsJob) + 256) + sizeof(MixJob) + 256) + 16 * 1024 * 8 + 8192;
 }
 
@@ -470,8 +482,10 @@ static int eval_chains(sacopt_ctx *c, const ProfDesc &pd, const std::vector<DevF
   if (!lead) return 0;
   int max_n = 0;
   for (int ci : todo_s[nstage - 1]) max_n = fr[chains[ci].frame].n > max_n ? fr[chains[ci].frame].n : max_n;
-  // windows long enough are cut into 4 chunks so that the stages overlap (stage state is carried)
-  const int chunk = (max_n >= 8 * LMS_CHUNK) ? ((max_n + 4 * LMS_CHUNK - 1) / (4 * LMS_CHUNK)) * LMS_CHUNK : (max_n > 0 ? max_n : 1);
+  // windows long enough are cut into ROUND_CHUNKS chunks so that the stages overlap (stage state is carried);
+  // the round ends one follower-chunk after the lead stage's last chunk
+  constexpr int ROUND_CHUNKS = 8;
+  const int chunk = (max_n >= 8 * LMS_CHUNK) ? ((max_n + ROUND_CHUNKS * LMS_CHUNK - 1) / (ROUND_CHUNKS * LMS_CHUNK)) * LMS_CHUNK : (max_n > 0 ? max_n : 1);
   const int nchunk = max_n > 0 ? (max_n + chunk - 1) / chunk : 1;
   const bool carry = nchunk > 1;
   std::vector<std::vector<double *>> state(nstage);
@@ -592,7 +606,6 @@ static int eval_chains(sacopt_ctx *c, const ProfDesc &pd, const std::vector<DevF
 // dominant stage alone. Everything is enqueued without host synchronisation, so a caller can
 // overlap it with work on c->st (the optimizer rounds). Results are identical to eval_chains.
 // `done` receives an event recorded when the last stage has finished.
-#define PIPE_CHUNK (44 * LMS_CHUNK) /* 22528 samples */
 static int final_pass_enqueue(sacopt_ctx *c, const ProfDesc &pd, const std::vector<DevFrame> &fr, std::vector<Chain> &chains,
                               hipEvent_t *done) {
   const int nstage = pd.nlms + 2, last = pd.nlms + 1;
@@ -711,6 +724,7 @@ static int final_pass_enqueue(sacopt_ctx *c, const ProfDesc &pd, const std::vect
   if (sacopt_launch_lpc3(d_lpc, nch, max_n, c->sB)) { c->err = "LPC3 launch failed"; return 1; }
   HIPCK(c, hipEventRecord(ev_lpc, c->sB));
   HIPCK(c, hipStreamWaitEvent(c->sA, ev_lpc, 0));
+  hipStream_t last_stream = c->sB;
   for (int k = 0; k < nchunk; k++) {
     hipEvent_t a, b, e1;
     HIPCK(c, hipEventCreate(&a));
@@ -723,12 +737,24 @@ static int final_pass_enqueue(sacopt_ctx *c, const ProfDesc &pd, const std::vect
     if (new_event(&e1)) return 1;
     HIPCK(c, hipEventRecord(e1, c->sA));
     HIPCK(c, hipStreamWaitEvent(c->sB, e1, 0));
-    for (int q = 1; q < pd.nlms; q++)
-      if (sacopt_launch_lms(pd.lms[q].S, pd.lms[q].D, d_lms[q][k], n_lms[q][k], c->d_tab, c->bits, c->sB)) { c->err = "k_lms launch failed"; return 1; }
-    if (sacopt_launch_mix(pd.nlms, d_mix[k], n_mix[k], c->sB)) { c->err = "k_mix launch failed"; return 1; }
+    // second LMS stage on sB, everything behind it on sD: three pipeline stages per chunk, so that the
+    // followers of chunk k together take no longer than the lead stage of chunk k+1
+    hipStream_t fs = c->sB;
+    for (int q = 1; q < pd.nlms; q++) {
+      if (sacopt_launch_lms(pd.lms[q].S, pd.lms[q].D, d_lms[q][k], n_lms[q][k], c->d_tab, c->bits, fs)) { c->err = "k_lms launch failed"; return 1; }
+      if (q == 1 && c->sD) {
+        hipEvent_t e2;
+        if (new_event(&e2)) return 1;
+        HIPCK(c, hipEventRecord(e2, c->sB));
+        HIPCK(c, hipStreamWaitEvent(c->sD, e2, 0));
+        fs = c->sD;
+      }
+    }
+    if (sacopt_launch_mix(pd.nlms, d_mix[k], n_mix[k], fs)) { c->err = "k_mix launch failed"; return 1; }
+    last_stream = fs;
   }
   if (new_event(done)) return 1;
-  HIPCK(c, hipEventRecord(*done, c->sB));
+  HIPCK(c, hipEventRecord(*done, last_stream));  // the mixer of the last chunk ran there
   return 0;
 }
 
@@ -974,7 +1000,7 @@ static size_t optimize_bytes(const ProfDesc &pd, int ncoef_loop, const std::vect
   for (int i = 0; i < ncoef_loop; i++)
     if (pd.nprefix[0] > i && grid[i].size() > lpc_jobs) lpc_jobs = grid[i].size();
   lpc_jobs += 1;  // the baseline chain rides along with the first round
-  return total_cand * (chain_bytes(pd, wn) + 1024 + sizeof(LpcJob)) + 32768 + lpc_jobs * (lpc_scratch_bytes(pd.type, wn) + 256);
+  return total_cand * (chain_bytes(pd, wn) + 8192 + sizeof(LpcJob)) + 32768 + lpc_jobs * (lpc_scratch_bytes(pd.type, wn) + 256);
 }
 
 // The search itself, on frames already staged (fr[f].from/n = optimisation window), all on c->st.
