@@ -66,7 +66,7 @@ def pmc_traffic():
         with open(files[-1]) as f:
             ks = json.load(f)["kernels"]
         for name, v in ks.items():
-            if name.startswith("k_lms<1280"):
+            if name.startswith("k_lms1c"):
                 return v["hbm_bytes_per_dispatch"]
     except (OSError, KeyError, ValueError):
         pass
@@ -152,7 +152,7 @@ def main():
                                    "full optimizer population (84 GetCost per frame) + final full-frame predict (BASELINE configs[2])",
                        "frames_per_gpu": nfr, "candidates_per_frame": int(rows[0]), "parallelism": f"frames sharded x{world}, no collective"},
             "algorithmic_tflops_whole_path": cand_units * world * args.steps * FLOPS_UNIT_HIGH / dt / 1e12,
-            "roofline": {"bound": "mfma", "kernel": "k_lms<1280,640>",
+            "roofline": {"bound": "mfma", "kernel": "k_lms1c",
                          "note": "FP64 compute bound (78.6 TFLOP/s vector = matrix FP64 peak); the real ceiling is the dependent-add "
                                  "latency of the serial 1920-term sums, the matrix pipe is used as an exact f64 adder, not a GEMM",
                          "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -117,10 +117,11 @@ int sacopt_lpc3_pair(sacopt_ctx *ctx, double alpha, const int32_t *s0, const int
 int sacopt_rls_run(sacopt_ctx *ctx, int nst, double alpha, const double *pv, const double *val,
                    int len, double *p);
 
-/* Timing of the last call, measured with HIP events on the library's own stream: total device
- * ms, and for the dominant kernel (the first = longest LMS stage of the profile, e.g.
- * k_lms<1280,640>): summed launch durations in ms, launch count and stereo samples processed.
- * No counterpart in the reference (measurement only). */
+/* Timing of the last call, measured with HIP events on the library's own streams: total device
+ * ms, and for the dominant kernel (high profile: k_lms1c, the per-channel LMSADA2(1280,640)
+ * kernel; other profiles: their first LMS stage): summed launch durations in ms, launch count
+ * and stereo samples processed by those launches. No counterpart in the reference (measurement
+ * only). */
 int sacopt_last_timing(const sacopt_ctx *ctx, double *total_ms, double *lms_ms, int *lms_launches,
                        long long *lms_units);
 

@@ -240,7 +240,7 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
       // the walked input and must reproduce the next walked input bit for bit -- by induction
       // from x_0 = 0 the result then IS the sequential sum. A mismatch pins the first wrong
       // boundary to the value P2 just computed and repeats (progress >= 1 segment per round).
-      static_assert(T == 1920 && NT == 512, "SPEC is laid out for the (1280,640) stage with 8 waves");
+      static_assert(T == 1920 && NT >= 512, "SPEC is laid out for the (1280,640) stage, phases on waves 0..7");
       // waves 0..7: channel = wave&1, candidate = wave>>1, so that the two channels' lead waves
       // (0 and 1) and each channel's four candidate waves sit on different SIMDs
       const int sc = wave & 1, sm = wave >> 1;
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
       }
       __syncthreads();
       STAMP(1);
-      if (!(dbg & 32)) {  // P1: exact segment sums from candidate inputs base + m*ulp
+      if (sm < 4 && !(dbg & 32)) {  // P1: exact segment sums from candidate inputs base + m*ulp
         const double st = sBase[sc][jD] + (double)sm * sU[sc][jD];
         sOut[sc][jD][sm] = mfma_pass30(paddr, st);
       }
@@ -424,7 +424,7 @@ __device__ __forceinline__ double rsq_emul2(double a, const float *tab, int bits
 __device__ __forceinline__ int ulp_shift(int v, int ea, int eb) {  // offset in ulps 2^ea -> ulps 2^eb (guess only)
   int ks = (ea && eb) ? ea - eb : 0;
   ks = ks > 31 ? 31 : (ks < -31 ? -31 : ks);
-  return ks >= 0 ? (int)((uint32_t)v << ks) : (v >> (-ks));
+  return ks >= 0 ? (int)((uint32_t)v << ks) : ((v + (1 << (-ks - 1))) >> (-ks));  // to nearest: the likelier of the two outcomes
 }
 
 __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs, const float *__restrict__ gtab, int bits) {
@@ -1241,12 +1241,17 @@ extern "C" int sacopt_lms_state_doubles(int S, int D) {  // 2 * R * NT of the ma
   if (S == 8 && D == 4) return 2 * 1 * 64;
   return 0;
 }
+// Which kernel a (1280,640) launch of `njobs` chains uses: 1 = k_lms1c (one workgroup per channel, while that
+// still leaves every workgroup a CU of its own), 0 = k_lms<1280,640,...> (one workgroup per chain).
+extern "C" int sacopt_lms_variant(int S, int D, int njobs, int bits) {
+  if (S != 1280 || D != 640) return 0;
+  return (!((bits >> 8) & (8 | 256)) && (njobs <= 100 || ((bits >> 8) & 512))) ? 1 : 0;
+}
 extern "C" int sacopt_launch_lms(int S, int D, const LmsJob *jobs, int njobs, const float *tab, int bits,
                                  hipStream_t st) {
   if (njobs <= 0) return 0;
   if (S == 1280 && D == 640) {
-    // one workgroup per channel while that still leaves every workgroup a CU of its own
-    if (!((bits >> 8) & (8 | 256)) && (njobs <= 100 || ((bits >> 8) & 512))) hipLaunchKernelGGL(k_lms1c, dim3(2 * njobs), dim3(L1_NT), 0, st, jobs, tab, bits);
+    if (sacopt_lms_variant(S, D, njobs, bits)) hipLaunchKernelGGL(k_lms1c, dim3(2 * njobs), dim3(L1_NT), 0, st, jobs, tab, bits);
     else if ((bits >> 8) & 8) hipLaunchKernelGGL((k_lms<1280, 640, 1024, 4, 2048, false>), dim3(njobs), dim3(1024), 0, st, jobs, tab, bits);
     else hipLaunchKernelGGL((k_lms<1280, 640, 512, 8, 2048, true>), dim3(njobs), dim3(512), 0, st, jobs, tab, bits);
   }

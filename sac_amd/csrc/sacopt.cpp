@@ -22,6 +22,7 @@
 extern "C" {
 int sacopt_lms_state_doubles(int S, int D);
 int sacopt_launch_lms(int S, int D, const LmsJob *jobs, int njobs, const float *tab, int bits, hipStream_t st);
+int sacopt_lms_variant(int S, int D, int njobs, int bits);
 int sacopt_launch_lpc3(const LpcJob *jobs, int njobs, int max_n, hipStream_t st);
 int sacopt_launch_lpc2(const LpcJob *jobs, int njobs, int max_n, hipStream_t st);
 int sacopt_launch_mix(int ns, const MixJob *jobs, int njobs, hipStream_t st);
@@ -562,7 +563,8 @@ static int eval_chains(sacopt_ctx *c, const ProfDesc &pd, const std::vector<DevF
       if (n_jobs[s]) {
         if (s <= pd.nlms) {
           const StageDesc &sd = pd.lms[s - 1];
-          const bool dominant = (s == 1);  // longest LMS stage of the profile: timed for the roofline
+          // the dominant kernel (k_lms1c for the high profile, the first LMS stage otherwise) is timed for the roofline
+          const bool dominant = (s == 1) && (sd.S != 1280 || sacopt_lms_variant(sd.S, sd.D, n_jobs[s], c->bits));
           hipEvent_t a = nullptr, b = nullptr;
           if (dominant) {
             HIPCK(c, hipEventCreate(&a));
@@ -726,14 +728,19 @@ static int final_pass_enqueue(sacopt_ctx *c, const ProfDesc &pd, const std::vect
   HIPCK(c, hipStreamWaitEvent(c->sA, ev_lpc, 0));
   hipStream_t last_stream = c->sB;
   for (int k = 0; k < nchunk; k++) {
-    hipEvent_t a, b, e1;
-    HIPCK(c, hipEventCreate(&a));
-    HIPCK(c, hipEventCreate(&b));
-    HIPCK(c, hipEventRecord(a, c->sA));
+    hipEvent_t a = nullptr, b = nullptr, e1;
+    const bool dominant = pd.lms[0].S != 1280 || sacopt_lms_variant(pd.lms[0].S, pd.lms[0].D, n_lms[0][k], c->bits);
+    if (dominant) {
+      HIPCK(c, hipEventCreate(&a));
+      HIPCK(c, hipEventCreate(&b));
+      HIPCK(c, hipEventRecord(a, c->sA));
+    }
     if (sacopt_launch_lms(pd.lms[0].S, pd.lms[0].D, d_lms[0][k], n_lms[0][k], c->d_tab, c->bits, c->sA)) { c->err = "k_lms launch failed"; return 1; }
-    HIPCK(c, hipEventRecord(b, c->sA));
-    c->lms_ev.push_back({a, b});
-    c->lms_units += units[k];
+    if (dominant) {
+      HIPCK(c, hipEventRecord(b, c->sA));
+      c->lms_ev.push_back({a, b});
+      c->lms_units += units[k];
+    }
     if (new_event(&e1)) return 1;
     HIPCK(c, hipEventRecord(e1, c->sA));
     HIPCK(c, hipStreamWaitEvent(c->sB, e1, 0));
