@@ -257,3 +257,56 @@ void ref_remap_map(const int32_t *src, int n, const int32_t *pred, const int32_t
 }
 
 }  // extern "C"
+
+namespace {
+// Frame record exactly as FrameCoder::WriteEncoded lays it out (codec.cpp:480-503): u32 numsamples, then per
+// channel u32 blocksize, u16 flag (bit 9 = mapped, low bits = maxbpn), payload. Little-endian.
+int pack_frame(FrameCoder &fc, uint8_t *out, int cap) {
+  std::vector<uint8_t> v;
+  auto p32 = [&](uint32_t x) { for (int i = 0; i < 4; i++) v.push_back((x >> (8 * i)) & 0xff); };
+  auto p16 = [&](uint32_t x) { for (int i = 0; i < 2; i++) v.push_back((x >> (8 * i)) & 0xff); };
+  p32(fc.numsamples);
+  for (int ch = 0; ch < 2; ch++) {
+    const uint32_t blocksize = fc.encoded[ch].GetBufPos();
+    p32(blocksize);
+    uint16_t flag = 0;
+    if (fc.framestats[ch].enc_mapped) { flag |= (1 << 9); flag |= fc.framestats[ch].maxbpn_map; }
+    else flag |= fc.framestats[ch].maxbpn;
+    p16(flag);
+    v.insert(v.end(), fc.encoded[ch].GetBuf().begin(), fc.encoded[ch].GetBuf().begin() + blocksize);
+  }
+  if ((int)v.size() > cap) return -(int)v.size();
+  memcpy(out, v.data(), v.size());
+  return (int)v.size();
+}
+}  // namespace
+
+extern "C" {
+// The reference's own frame: FrameCoder::Predict() + Encode() (codec.cpp:442-472) -> frame record bytes.
+int ref_encode_frame(int profile, const int32_t *s0, const int32_t *s1, int total, uint8_t *out, int cap) {
+  CoutMute mute;
+  FrameCoder fc(2, total, profile);
+  for (int i = 0; i < total; i++) { fc.samples[0][i] = s0[i]; fc.samples[1][i] = s1[i]; }
+  fc.SetNumSamples(total);
+  fc.Predict();
+  fc.Encode();
+  return pack_frame(fc, out, cap);
+}
+// The reference's bit-plane coder fed with residuals computed elsewhere (the HIP path): what a host that
+// calls libsacopt for FrameCoder::Predict and keeps Encode()/WriteEncoded() produces.
+int ref_encode_residuals(int profile, const int32_t *s0, const int32_t *s1, int total, const int32_t *u0,
+                         const int32_t *u1, const int32_t *m0, const int32_t *m1, const int *maxbpn,
+                         uint8_t *out, int cap) {
+  CoutMute mute;
+  FrameCoder fc(2, total, profile);
+  load_frame(fc, s0, s1, total);  // samples + Remap tables for MapEncoder (codec.cpp:448-452, :258)
+  for (int i = 0; i < total; i++) {
+    fc.s2u_error[0][i] = u0[i]; fc.s2u_error[1][i] = u1[i];
+    fc.s2u_error_map[0][i] = m0[i]; fc.s2u_error_map[1][i] = m1[i];
+  }
+  fc.framestats[0].maxbpn = maxbpn[0]; fc.framestats[1].maxbpn = maxbpn[1];
+  fc.framestats[0].maxbpn_map = maxbpn[2]; fc.framestats[1].maxbpn_map = maxbpn[3];
+  fc.Encode();
+  return pack_frame(fc, out, cap);
+}
+}

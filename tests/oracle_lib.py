@@ -191,5 +191,27 @@ class Ref(_Lib):
         return best, trace[:rows].copy()
 
 
+def _ref_encode(self, fn, *args, total):
+    cap = 16 * total + 4096
+    out = np.zeros(cap, np.uint8)
+    n = fn(*args, _ptr(out), C.c_int(cap))
+    assert n > 0
+    return out[:n].tobytes()
+
+
+def ref_encode_frame(ref, profile, s0, s1):
+    """Frame record bytes (FrameCoder::WriteEncoded layout) of the reference's own Predict()+Encode()."""
+    s0 = np.ascontiguousarray(s0, dtype=np.int32); s1 = np.ascontiguousarray(s1, dtype=np.int32)
+    return _ref_encode(ref, ref.lib.ref_encode_frame, C.c_int(profile), _ptr(s0), _ptr(s1), C.c_int(len(s0)), total=len(s0))
+
+
+def ref_encode_residuals(ref, profile, s0, s1, res):
+    """Frame record bytes of the reference's Encode() fed with residuals computed elsewhere (dict u0,u1,m0,m1,maxbpn)."""
+    s0 = np.ascontiguousarray(s0, dtype=np.int32); s1 = np.ascontiguousarray(s1, dtype=np.int32)
+    a = [np.ascontiguousarray(res[k], dtype=np.int32) for k in ("u0", "u1", "m0", "m1", "maxbpn")]
+    return _ref_encode(ref, ref.lib.ref_encode_residuals, C.c_int(profile), _ptr(s0), _ptr(s1), C.c_int(len(s0)),
+                       *[_ptr(x) for x in a], total=len(s0))
+
+
 def have_ref():
     return os.path.exists(_REF_SO)

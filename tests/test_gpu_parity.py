@@ -169,3 +169,24 @@ def test_encode_frames_overlapped(ctx, oracle):
         assert same_bits(best[f], ob), f
         ref = oracle.predict(2, L, R)
         assert np.array_equal(outs[f]["e0"], ref["e0"]) and np.array_equal(outs[f]["e1"], ref["e1"]), f
+
+
+# ---------------------------------------------------------------- stream level (.sac frame records)
+def test_frame_records_byte_identical():
+    # "ref+opt": the stream is coded with the base profile, so a host that takes FrameCoder::Predict from the
+    # GPU and keeps the reference's Encode()/WriteEncoded() must write the reference's bytes. The bit-plane /
+    # range coder here IS the reference's (oracle/_ref, built in the container, test-only); where it is absent
+    # the test is skipped. Uses the CPU's own rsqrtss (probed) on both sides, as a real encoder run would.
+    import oracle_lib
+    if not oracle_lib.have_ref():
+        pytest.skip("oracle/_ref not built")
+    ref = oracle_lib.Ref()
+    c = sacopt.Context(0)  # table probed from this host's CPU = what the reference binary uses here
+    try:
+        frames = [stereo_clip(70, 20000), stereo_clip(71, 17001)]
+        for prof in (0, 1, 2):
+            best, outs = c.encode(prof, frames, maps=True)
+            for (L, R), o in zip(frames, outs):
+                assert oracle_lib.ref_encode_residuals(ref, prof, L, R, o) == oracle_lib.ref_encode_frame(ref, prof, L, R), prof
+    finally:
+        c.close()

@@ -82,3 +82,13 @@ def test_samples_beyond_remap_table(pair):
         a = o.predict(prof, L, R, maps=True); b = r.predict(prof, L, R, maps=True)
         for k in a:
             assert np.array_equal(a[k], b[k]), (prof, k)
+
+
+def test_frame_record_bytes_from_oracle_residuals(pair):
+    # the reference's Encode()/WriteEncoded() fed with the oracle's residuals writes the reference's own frame bytes
+    import oracle_lib
+    o, r = pair
+    L, R = stereo_clip(25, 6000)
+    for prof in (0, 1, 2):
+        res = o.predict(prof, L, R, maps=True)
+        assert oracle_lib.ref_encode_residuals(r, prof, L, R, res) == oracle_lib.ref_encode_frame(r, prof, L, R), prof
