@@ -154,7 +154,7 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
 
   const LmsJob job = jobs[blockIdx.x];
   const int tid = threadIdx.x, t0 = job.t0, tend = job.t0 + job.n;
-  const int dbg = bits >> 8;  // DEBUG ablation flags
+  const int dbg = bits >> 8;  // A/B timing switches (tools/ablate.py): 2 = skip the update, 16 = single P2 pass
   bits &= 0xff;
   for (int i = tid; i < (2 << bits); i += NT) tab[i] = gtab[i];
   for (int i = tid; i < 2 * RL; i += NT) (&ring[0][0])[i] = 0.;
@@ -207,10 +207,7 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
       }
     }
   };
-  long long tmr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tq = 0;  // DEBUG phase timers (dbg & 128)
-#define STAMP(i) do { if (dbg & 128) { long long now_ = __builtin_amdgcn_s_memtime(); tmr[i] += now_ - tq; tq = now_; } } while (0)
   for (int t = t0; t < tend; t++) {
-    if (dbg & 128) tq = __builtin_amdgcn_s_memtime();
     if ((t & (CH - 1)) == 0) {
       if (t > t0) flush(t - CH, t);
       for (int idx = tid; idx < 2 * CH; idx += NT) {
@@ -225,10 +222,9 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
 #pragma unroll
     for (int r = 0; r < R; r++) {
       h[r] = ring[hsel[r]][(t + hoff[r]) & M];
-      if (valid[r] && !(dbg & 4)) (&prods[0][0])[paddr[r]] = w[r] * h[r];
+      if (valid[r]) (&prods[0][0])[paddr[r]] = w[r] * h[r];
     }
     __syncthreads();
-    STAMP(0);
     // ---- pred = 0.; for i: pred += w[i]*hist[i]  -- strict order, on the matrix pipe
     if constexpr (SPEC) {
       // The 1920-term chain is cut into 16 segments of 120. A segment's exact output depends on
@@ -249,7 +245,7 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
       const uint32_t paddr = (uint32_t)(uintptr_t)&prods[sc][jA * SEGP + kA];
       const int j16 = lane & 15;
       double gA = 0., gBase = 0., gU = 0., gIU = 0.;  // lanes 0..15 (and their mod-16 copies): per-boundary values
-      if (sm == 0 && !(dbg & 64)) {  // P0: segment sums from zero -> guesses of the segment inputs
+      if (sm == 0) {  // P0: segment sums from zero -> guesses of the segment inputs
         const double a = mfma_pass30(paddr, 0.);
         gA = __shfl(a, dl);  // lane l now holds A_(l&15)
         double sh = gA;      // exclusive prefix over the 16 segments (any order: only a guess)
@@ -264,13 +260,11 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
         if (lane < 16) { sBase[sc][lane] = gBase; sU[sc][lane] = gU; sInvU[sc][lane] = gIU; }
       }
       __syncthreads();
-      STAMP(1);
-      if (sm < 4 && !(dbg & 32)) {  // P1: exact segment sums from candidate inputs base + m*ulp
+      if (sm < 4) {  // P1: exact segment sums from candidate inputs base + m*ulp
         const double st = sBase[sc][jD] + (double)sm * sU[sc][jD];
         sOut[sc][jD][sm] = mfma_pass30(paddr, st);
       }
       __syncthreads();
-      STAMP(2);
       if (sm == 0) {
         // table entry (j, m): next segment's offset (in its ulps) if segment j's input offset is m
         const int tj = lane >> 2, tm = lane & 3;
@@ -304,15 +298,12 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
             if (lane == j + 1) myd = d;
           }
           if (lane > first && lane < 16) x = gBase + (double)myd * gU;
-          STAMP(3);
           // ---- P2: verify every boundary
           const double xs = __shfl(x, jD);
           res = mfma_pass30(paddr, xs);
           const double xn = __shfl(x, jD < 15 ? jD + 1 : 15);
           const bool bad = (jD < 15) && (__double_as_longlong(res) != __double_as_longlong(xn));
           const unsigned long long mask = __ballot(bad);
-          STAMP(4);
-          if (dbg & 128) tmr[6] += 1;
           if (mask == 0ull || (dbg & 16)) break;
           int f = 0;  // first failing segment (D-layout lane of chain j: 16*(j&3) + 4*(j>>2))
           while (f < 15 && !((mask >> (16 * (f & 3) + 4 * (f >> 2))) & 1ull)) f++;
@@ -331,7 +322,6 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
     } else
     if (wave == 0) {
       double acc = 0.;
-      if (dbg & 1) acc = mp[t & 7]; else
       if constexpr (T4 % 16 == 0) {
         acc = mfma_chain_lds<T4 / 16>((uint32_t)(uintptr_t)mp);
       } else {
@@ -349,7 +339,6 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
       }
     }
     __syncthreads();
-    STAMP(5);
     // ---- Update (nlms.h:114-129)
     const double e0 = ring[0][t & M] - predv[0];
     const double e1 = ring[1][t & M] - predv[1];
@@ -362,14 +351,8 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
         w[r] += (mu[r] * grad * rsq_emul(eg[r] + 0.001, tab, bits));
       }
     }
-    STAMP(7);
   }
   if (tend > t0) flush((tend - 1) & ~(CH - 1), tend);
-  if (dbg & 128) {
-    __syncthreads();
-    if (tid == 0) for (int i = 0; i < 8; i++) job.p[0][i] = (double)tmr[i];
-  }
-#undef STAMP
   if (job.state) {
 #pragma unroll
     for (int r = 0; r < R; r++) {

@@ -40,6 +40,7 @@ struct sacopt_ctx {
   hipStream_t st = nullptr;
   hipStream_t sA = nullptr, sB = nullptr;  // final-pass pipeline: dominant LMS stage / everything else
   hipStream_t sC = nullptr;                // follower stages of the optimizer rounds
+  hipStream_t sAall = nullptr;             // lead stage of the full-frame pass when it has more workgroups than sA's reserved CUs
   hipStream_t sD = nullptr;                // final-pass pipeline: stages behind the second LMS stage (may be NULL)
   std::vector<hipEvent_t> pipe_ev;         // events of the last call's pipeline
   float *d_tab = nullptr;
@@ -204,22 +205,47 @@ extern "C" int sacopt_create(int device, const float *rsqrt_tab, int rsqrt_bits,
   if (const char *dbg = getenv("SACOPT_DBG_ALL")) c->bits |= atoi(dbg) << 8;  // kernel-variant switches for A/B timing (kernels.hip)
   auto fail = [&](const char *what) { g_create_error = what; delete c; return 1; };
   if (hipSetDevice(device) != hipSuccess) return fail("hipSetDevice failed");
-  if (hipStreamCreate(&c->st) != hipSuccess || hipStreamCreate(&c->sA) != hipSuccess || hipStreamCreate(&c->sB) != hipSuccess)
-    return fail("hipStreamCreate failed");
+  // Streams and hardware queues. HIP multiplexes same-priority streams onto a small pool of in-order hardware
+  // queues (3 usable here: a 4th normal-priority stream shared a queue with the pre-enqueued full-frame
+  // pipeline and serialised behind it; priorities have their own pools, but a second high-priority stream
+  // shares the first one's queue and a low-priority stream never got scheduled). A stream created with an
+  // explicit CU mask gets a queue of its own, and the mask is useful in itself: the lead stage of the
+  // full-frame pass -- 2 workgroups per frame, each a CU-filling serial chain that bounds the whole call --
+  // gets 32 CUs to itself, everything else runs on the others (sharing CUs with the follower stages cost
+  // that kernel 12 %). SACOPT_CUMASK=0 falls back to unmasked streams (lead/follower split by priority).
+  bool masked = false;
   {
-    // HIP multiplexes same-priority streams onto a small pool of in-order hardware queues (3 usable here);
-    // a 4th normal-priority stream would share a queue with the pre-enqueued full-frame pipeline and
-    // serialise behind it. Priorities have their own queue pools, so the follower stream takes another level.
+    hipDeviceProp_t prop;
+    const char *env = getenv("SACOPT_CUMASK");
+    if (!(env && atoi(env) == 0) && hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount >= 128) {
+      const int words = (prop.multiProcessorCount + 31) / 32;
+      std::vector<uint32_t> ma(words, 0u), mr(words, 0xffffffffu);
+      ma[0] = 0xffffffffu; mr[0] = 0u;
+      if (prop.multiProcessorCount % 32) mr[words - 1] = (1u << (prop.multiProcessorCount % 32)) - 1u;
+      masked = hipExtStreamCreateWithCUMask(&c->sA, words, ma.data()) == hipSuccess &&
+               hipExtStreamCreateWithCUMask(&c->st, words, mr.data()) == hipSuccess &&
+               hipExtStreamCreateWithCUMask(&c->sB, words, mr.data()) == hipSuccess &&
+               hipExtStreamCreateWithCUMask(&c->sC, words, mr.data()) == hipSuccess &&
+               hipExtStreamCreateWithCUMask(&c->sD, words, mr.data()) == hipSuccess;
+      if (masked) {
+        std::vector<uint32_t> mall(mr);
+        mall[0] = 0xffffffffu;
+        masked = hipExtStreamCreateWithCUMask(&c->sAall, words, mall.data()) == hipSuccess;
+      }
+      if (!masked) {
+        (void)hipGetLastError();
+        hipStream_t *all[6] = {&c->sA, &c->st, &c->sB, &c->sC, &c->sD, &c->sAall};
+        for (hipStream_t *p : all) if (*p) { (void)hipStreamDestroy(*p); *p = nullptr; }
+      }
+    }
+  }
+  if (!masked) {
+    if (hipStreamCreate(&c->st) != hipSuccess || hipStreamCreate(&c->sA) != hipSuccess || hipStreamCreate(&c->sB) != hipSuccess)
+      return fail("hipStreamCreate failed");
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
     if (hipStreamCreateWithPriority(&c->sC, hipStreamDefault, hi) != hipSuccess) return fail("hipStreamCreateWithPriority failed");
-    // A stream with an explicit CU mask gets a hardware queue of its own (queues are only shared between
-    // streams with the same mask); the mask itself is left full.
-    if (!getenv("SACOPT_NO_SD")) {
-      uint32_t mask[8];
-      for (int k = 0; k < 8; k++) mask[k] = 0xffffffffu;
-      if (hipExtStreamCreateWithCUMask(&c->sD, 8, mask) != hipSuccess) { (void)hipGetLastError(); c->sD = nullptr; }
-    }
+    c->sD = nullptr;  // full-frame followers all on sB
   }
   if (hipMalloc(&c->d_tab, sizeof(float) * (2 << bits)) != hipSuccess) return fail("hipMalloc(table) failed");
   if (hipMemcpy(c->d_tab, tab.data(), sizeof(float) * (2 << bits), hipMemcpyHostToDevice) != hipSuccess) return fail("table upload failed");
@@ -248,6 +274,7 @@ extern "C" void sacopt_destroy(sacopt_ctx *c) {
   if (c->sB) (void)hipStreamDestroy(c->sB);
   if (c->sC) (void)hipStreamDestroy(c->sC);
   if (c->sD) (void)hipStreamDestroy(c->sD);
+  if (c->sAall) (void)hipStreamDestroy(c->sAall);
   if (c->st) (void)hipStreamDestroy(c->st);
   delete c;
 }
@@ -485,7 +512,7 @@ static int eval_chains(sacopt_ctx *c, const ProfDesc &pd, const std::vector<DevF
   for (int ci : todo_s[nstage - 1]) max_n = fr[chains[ci].frame].n > max_n ? fr[chains[ci].frame].n : max_n;
   // windows long enough are cut into ROUND_CHUNKS chunks so that the stages overlap (stage state is carried);
   // the round ends one follower-chunk after the lead stage's last chunk
-  constexpr int ROUND_CHUNKS = 8;
+  constexpr int ROUND_CHUNKS = 16;
   const int chunk = (max_n >= 8 * LMS_CHUNK) ? ((max_n + ROUND_CHUNKS * LMS_CHUNK - 1) / (ROUND_CHUNKS * LMS_CHUNK)) * LMS_CHUNK : (max_n > 0 ? max_n : 1);
   const int nchunk = max_n > 0 ? (max_n + chunk - 1) / chunk : 1;
   const bool carry = nchunk > 1;
@@ -718,14 +745,17 @@ static int final_pass_enqueue(sacopt_ctx *c, const ProfDesc &pd, const std::vect
     c->pipe_ev.push_back(*e);
     return 0;
   };
+  // sA owns 32 CUs: right for a handful of frames (2 workgroups each), wrong for a large batch
+  const int lead_wgs = nch * (sacopt_lms_variant(pd.lms[0].S, pd.lms[0].D, nch, c->bits) ? 2 : 1);
+  hipStream_t sLead = (c->sAall && lead_wgs > 32) ? c->sAall : c->sA;
   hipEvent_t ev_in, ev_lpc;
   if (new_event(&ev_in) || new_event(&ev_lpc)) return 1;
   HIPCK(c, hipEventRecord(ev_in, c->st));  // inputs + job tables were staged on c->st
   HIPCK(c, hipStreamWaitEvent(c->sB, ev_in, 0));
-  HIPCK(c, hipStreamWaitEvent(c->sA, ev_in, 0));
+  HIPCK(c, hipStreamWaitEvent(sLead, ev_in, 0));
   if (sacopt_launch_lpc3(d_lpc, nch, max_n, c->sB)) { c->err = "LPC3 launch failed"; return 1; }
   HIPCK(c, hipEventRecord(ev_lpc, c->sB));
-  HIPCK(c, hipStreamWaitEvent(c->sA, ev_lpc, 0));
+  HIPCK(c, hipStreamWaitEvent(sLead, ev_lpc, 0));
   hipStream_t last_stream = c->sB;
   for (int k = 0; k < nchunk; k++) {
     hipEvent_t a = nullptr, b = nullptr, e1;
@@ -733,16 +763,16 @@ static int final_pass_enqueue(sacopt_ctx *c, const ProfDesc &pd, const std::vect
     if (dominant) {
       HIPCK(c, hipEventCreate(&a));
       HIPCK(c, hipEventCreate(&b));
-      HIPCK(c, hipEventRecord(a, c->sA));
+      HIPCK(c, hipEventRecord(a, sLead));
     }
-    if (sacopt_launch_lms(pd.lms[0].S, pd.lms[0].D, d_lms[0][k], n_lms[0][k], c->d_tab, c->bits, c->sA)) { c->err = "k_lms launch failed"; return 1; }
+    if (sacopt_launch_lms(pd.lms[0].S, pd.lms[0].D, d_lms[0][k], n_lms[0][k], c->d_tab, c->bits, sLead)) { c->err = "k_lms launch failed"; return 1; }
     if (dominant) {
-      HIPCK(c, hipEventRecord(b, c->sA));
+      HIPCK(c, hipEventRecord(b, sLead));
       c->lms_ev.push_back({a, b});
       c->lms_units += units[k];
     }
     if (new_event(&e1)) return 1;
-    HIPCK(c, hipEventRecord(e1, c->sA));
+    HIPCK(c, hipEventRecord(e1, sLead));
     HIPCK(c, hipStreamWaitEvent(c->sB, e1, 0));
     // second LMS stage on sB, everything behind it on sD: three pipeline stages per chunk, so that the
     // followers of chunk k together take no longer than the lead stage of chunk k+1

@@ -190,3 +190,25 @@ def test_frame_records_byte_identical():
                 assert oracle_lib.ref_encode_residuals(ref, prof, L, R, o) == oracle_lib.ref_encode_frame(ref, prof, L, R), prof
     finally:
         c.close()
+
+
+def test_predict_many_frames_kernel_variants(ctx, oracle):
+    # > 100 chains per launch use the two-channel LMS(1280,640) kernel, fewer use the per-channel one;
+    # with ragged lengths the later pipeline chunks drop below 100 jobs, so a chain's carried state
+    # passes from one kernel to the other. Everything must equal the one-frame-at-a-time results
+    # (per-channel kernel only) and, for sampled frames, the oracle.
+    lens = [16500 + 37 * i for i in range(98)] + [24600 + 11 * i for i in range(8)]
+    frames = [stereo_clip(200 + i % 7, n) for i, n in enumerate(lens)]
+    outs = ctx.predict(2, frames)
+    for i in (0, 57, 97, 98, 105):
+        L, R = frames[i]
+        one = ctx.predict(2, [(L, R)])[0]
+        for k in ("e0", "e1", "u0", "u1"):
+            assert np.array_equal(outs[i][k], one[k]), (i, k)
+    for i in (3, 101):
+        L, R = frames[i]
+        ref = oracle.predict(2, L, R)
+        assert np.array_equal(outs[i]["e0"], ref["e0"]) and np.array_equal(outs[i]["e1"], ref["e1"]), i
+    # identical inputs give identical outputs wherever they sit in the batch
+    for i in range(7, 98, 7):
+        assert np.array_equal(outs[i]["e0"][:16500], outs[0]["e0"][:16500])

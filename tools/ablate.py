@@ -15,4 +15,4 @@ modes = [int(a) for a in sys.argv[1:]] or [0, 8, 16, 16 + 32, 16 + 32 + 64, 2, 4
 for mode in modes:
     os.environ["SACOPT_DBG"] = str(mode)
     ctx.lms_pair(1280, 640, 1e-5, 5e-6, x0, x1); t = ctx.last_timing()
-    print(f"mode {mode:4d} (8=serial chain,16=single P2,32=no P1,64=no P0,2=no update,4=no product write): {2.4e6*t['total_ms']/n:8.0f} cyc/sample", flush=True)
+    print(f"mode {mode:4d} (256=two-channel kernel,8=serial chain,16=single P2,2=no update): {2.4e6*t['total_ms']/n:8.0f} cyc/sample", flush=True)
