@@ -26,7 +26,10 @@ struct LpcJob {
   int32_t *u[2];        // LPC2: s2u_error[ch]
   int32_t *umax;        // LPC2: [2] max s2u (must be zeroed before the launch)
   double alpha;
-  int32_t n, nsnap;     // nsnap = n / k  (k = 8 for LPC3, 32 for LPC2)
+  int32_t n, nsnap;     // this launch covers times [t0, n); nsnap = n / k  (k = 8 for LPC3, 32 for LPC2)
+  int32_t t0;           // chunk start (multiple of 512); 0 = from the beginning
+  double *cstate[2];    // [324] covariance + b carried between chunks (NULL = single launch)
+  double *estate[2];    // [24]  BlendErr running errors carried between chunks
   // scratch, per channel (released after the stage has run)
   double *snap[2];      // [nsnap][324] covariance (packed lower triangle) + b after every k-th Update
   double *sol[2];       // [nsnap][300] all-orders solutions (LPC2: [nsnap][24])

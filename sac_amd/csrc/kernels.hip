@@ -638,11 +638,20 @@ __global__ __launch_bounds__(384) void k_cov(const LpcJob *__restrict__ jobs) {
   __shared__ double ring[2][RL];
   const LpcJob &job = jobs[blockIdx.x];
   const int ch = blockIdx.y, oc = 1 - ch, lagb = (ch == 0) ? 1 : 0;
-  const int tid = threadIdx.x, n = job.n;
+  const int tid = threadIdx.x, n = job.n, t0 = job.t0;
   const double alpha = job.alpha;
   const int32_t *s0 = job.s[0], *s1 = job.s[1];
   double *snap = ch ? job.snap[1] : job.snap[0];
+  double *cst = ch ? job.cstate[1] : job.cstate[0];
   for (int i = tid; i < 2 * RL; i += 384) (&ring[0][0])[i] = 0.;
+  if (t0 > 0) {  // history before the chunk
+    __syncthreads();
+    for (int idx = tid; idx < 2 * (RL - CH); idx += 384) {
+      const int c = idx / (RL - CH), tau = t0 - (RL - CH) + (idx - c * (RL - CH));
+      const int32_t *ss = c ? s1 : s0;
+      if (tau >= 0) ring[c][tau & M] = (double)ss[tau];
+    }
+  }
   // element e: e < 300 -> c[j][i] (packed j(j+1)/2+i); 300..323 -> b[e-300]
   const int e = tid;
   const bool isc = e < LPC_TRI, isb = !isc && e < LPC_SNAP;
@@ -655,7 +664,8 @@ __global__ __launch_bounds__(384) void k_cov(const LpcJob *__restrict__ jobs) {
   };
   const int ai = haddr(i), aj = haddr(j);
   double cv = (isc && i == j) ? 1.0 : 0.0;  // cov.h:17
-  for (int t = 0; t < n; t++) {
+  if (t0 > 0 && cst && (isc || isb)) cv = cst[e];
+  for (int t = t0; t < n; t++) {
     if ((t & (CH - 1)) == 0) {
       __syncthreads();
       for (int idx = tid; idx < 2 * CH; idx += 384) {
@@ -671,6 +681,7 @@ __global__ __launch_bounds__(384) void k_cov(const LpcJob *__restrict__ jobs) {
     else if (isb) cv = alpha * cv + (hj * hi);
     if (((t + 1) % KS) == 0 && (isc || isb)) snap[(size_t)(t / KS) * LPC_SNAP + e] = cv;
   }
+  if (cst && (isc || isb)) cst[e] = cv;
 }
 
 // Cholesky::Factor + Solve for one snapshot (cholesky.cpp:16-77). Lane r owns matrix row r;
@@ -681,7 +692,7 @@ __global__ __launch_bounds__(64) void k_chol(const LpcJob *__restrict__ jobs) {
   constexpr int N = LPC_N;
   constexpr double REGP = FAST ? 0. : 500.;
   const LpcJob &job = jobs[blockIdx.y >> 1];
-  const int ch = blockIdx.y & 1, k = blockIdx.x, lane = threadIdx.x;
+  const int ch = blockIdx.y & 1, k = job.t0 / (FAST ? 32 : 8) + blockIdx.x, lane = threadIdx.x;
   if (k >= job.nsnap) return;
   const double *snap = (ch ? job.snap[1] : job.snap[0]) + (size_t)k * LPC_SNAP;
   double *solo = (ch ? job.sol[1] : job.sol[0]) + (size_t)k * (FAST ? N : LPC_TRI);
@@ -760,7 +771,7 @@ __global__ __launch_bounds__(256) void k_ssum(const LpcJob *__restrict__ jobs) {
   const LpcJob &job = jobs[blockIdx.y >> 1];
   const int ch = blockIdx.y & 1, n = job.n;
   const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
-  const int t = (int)(gid / LPC_N), o = (int)(gid % LPC_N);
+  const int t = job.t0 + (int)(gid / LPC_N), o = (int)(gid % LPC_N);
   if (t >= n) return;
   const int32_t *own = ch ? job.s[1] : job.s[0], *oth = ch ? job.s[0] : job.s[1];
   const int lagb = (ch == 0) ? 1 : 0;
@@ -781,8 +792,9 @@ __global__ __launch_bounds__(64) void k_serr(const LpcJob *__restrict__ jobs) {
   const int32_t *own = ch ? job.s[1] : job.s[0];
   const double *ss = ch ? job.ss[1] : job.ss[0];
   double *so = ch ? job.serr[1] : job.serr[0];
-  double serr = 0.;
-  int t = 0;
+  double *est = ch ? job.estate[1] : job.estate[0];
+  double serr = (job.t0 > 0 && est) ? est[lane] : 0.;
+  int t = job.t0;
   for (; t + 8 <= n; t += 8) {
     double q[8];
 #pragma unroll
@@ -801,13 +813,14 @@ __global__ __launch_bounds__(64) void k_serr(const LpcJob *__restrict__ jobs) {
     serr = 0.98 * serr + (1. - 0.98) * (e * e);
     so[(size_t)t * LPC_N + lane] = serr;
   }
+  if (est) est[lane] = serr;
 }
 
 // BlendErr weights (blend.h:38-45) + blended prediction (blend.h:15-17): thread per t
 __global__ __launch_bounds__(256) void k_pm(const LpcJob *__restrict__ jobs) {
   const LpcJob &job = jobs[blockIdx.y >> 1];
   const int ch = blockIdx.y & 1, n = job.n;
-  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int t = job.t0 + blockIdx.x * 256 + threadIdx.x;
   if (t >= n) return;
   const int32_t *own = ch ? job.s[1] : job.s[0];
   const double *ss = (ch ? job.ss[1] : job.ss[0]) + (size_t)t * LPC_N;
@@ -838,7 +851,7 @@ __global__ __launch_bounds__(256) void k_pm(const LpcJob *__restrict__ jobs) {
 __global__ __launch_bounds__(256) void k_pred2(const LpcJob *__restrict__ jobs) {
   const LpcJob &job = jobs[blockIdx.y >> 1];
   const int ch = blockIdx.y & 1, n = job.n;
-  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int t = job.t0 + blockIdx.x * 256 + threadIdx.x;
   if (t >= n) return;
   const int32_t *own = ch ? job.s[1] : job.s[0], *oth = ch ? job.s[0] : job.s[1];
   const int lagb = (ch == 0) ? 1 : 0;
@@ -1244,6 +1257,7 @@ extern "C" int sacopt_launch_lms(int S, int D, const LmsJob *jobs, int njobs, co
   else return 1;
   return hipGetLastError() != hipSuccess;
 }
+// max_n: longest span n - t0 of the jobs
 extern "C" int sacopt_launch_lpc3(const LpcJob *jobs, int njobs, int max_n, hipStream_t st) {
   if (njobs <= 0 || max_n <= 0) return 0;
   const int max_snap = max_n / 8;

@@ -411,7 +411,7 @@ static int lpc_scratch_alloc(sacopt_ctx *c, int type, LpcJob &j) {
 // job tables + carried state of the pipelined pass for one chain of n samples
 static size_t pipe_bytes(int n) {
   const size_t nchunk = (size_t)n / PIPE_CHUNK + 1;
-  return nchunk * (4 * (sizeof(LmsJob) + 256) + sizeof(MixJob) + 256) + 16 * 1024 * 8 + 8192;
+  return nchunk * (4 * (sizeof(LmsJob) + 256) + sizeof(MixJob) + 256 + sizeof(LpcJob) + 256) + 16 * 1024 * 8 + 16384;
 }
 
 // Run all chains through the cascade, re-using memoised stage outputs. `want_u`: also write s2u.
@@ -675,9 +675,30 @@ static int final_pass_enqueue(sacopt_ctx *c, const ProfDesc &pd, const std::vect
     j.alpha = ch.coefs[0];
     j.n = f.n;
     if (lpc_scratch_alloc(c, pd.type, j)) return 1;  // stays allocated for the whole call
+    for (int k = 0; k < 2; k++) {  // the LPC stage is chunked too: covariance / BlendErr state carried
+      j.cstate[k] = arena_alloc<double>(c, 324);
+      j.estate[k] = arena_alloc<double>(c, 24);
+      if (!j.cstate[k] || !j.estate[k]) { c->err = "device arena exhausted"; return 1; }
+    }
   }
-  LpcJob *d_lpc;
-  if (upload(c, lpc, &d_lpc)) return 1;
+  std::vector<LpcJob *> d_lpc(nchunk, nullptr);
+  std::vector<int> n_lpc(nchunk, 0), len_lpc(nchunk, 0);
+  for (int k = 0; k < nchunk; k++) {
+    const int t0 = k * PIPE_CHUNK;
+    std::vector<LpcJob> jobs;
+    for (int i = 0; i < nch; i++) {
+      const int n = fr[chains[i].frame].n;
+      if (t0 >= n) continue;
+      LpcJob j = lpc[i];
+      j.t0 = t0;
+      j.n = (n - t0 < PIPE_CHUNK) ? n : t0 + PIPE_CHUNK;
+      j.nsnap = j.n / 8;
+      len_lpc[k] = (j.n - t0 > len_lpc[k]) ? j.n - t0 : len_lpc[k];
+      jobs.push_back(j);
+    }
+    n_lpc[k] = (int)jobs.size();
+    if (!jobs.empty() && upload(c, jobs, &d_lpc[k])) return 1;
+  }
   std::vector<std::vector<LmsJob *>> d_lms(pd.nlms, std::vector<LmsJob *>(nchunk, nullptr));
   std::vector<std::vector<int>> n_lms(pd.nlms, std::vector<int>(nchunk, 0));
   std::vector<MixJob *> d_mix(nchunk, nullptr);
@@ -748,16 +769,25 @@ static int final_pass_enqueue(sacopt_ctx *c, const ProfDesc &pd, const std::vect
   // sA owns 32 CUs: right for a handful of frames (2 workgroups each), wrong for a large batch
   const int lead_wgs = nch * (sacopt_lms_variant(pd.lms[0].S, pd.lms[0].D, nch, c->bits) ? 2 : 1);
   hipStream_t sLead = (c->sAall && lead_wgs > 32) ? c->sAall : c->sA;
-  hipEvent_t ev_in, ev_lpc;
-  if (new_event(&ev_in) || new_event(&ev_lpc)) return 1;
+  hipEvent_t ev_in;
+  if (new_event(&ev_in)) return 1;
   HIPCK(c, hipEventRecord(ev_in, c->st));  // inputs + job tables were staged on c->st
   HIPCK(c, hipStreamWaitEvent(c->sB, ev_in, 0));
   HIPCK(c, hipStreamWaitEvent(sLead, ev_in, 0));
-  if (sacopt_launch_lpc3(d_lpc, nch, max_n, c->sB)) { c->err = "LPC3 launch failed"; return 1; }
-  HIPCK(c, hipEventRecord(ev_lpc, c->sB));
-  HIPCK(c, hipStreamWaitEvent(sLead, ev_lpc, 0));
+  // The LPC stage runs on sB two chunks ahead of the lead stage (it is ~10x cheaper), so only its first
+  // chunk is ever in front of the lead stage
+  std::vector<hipEvent_t> ev_lpc(nchunk, nullptr);
+  auto lpc_chunk = [&](int k) -> int {
+    if (k >= nchunk) return 0;
+    if (sacopt_launch_lpc3(d_lpc[k], n_lpc[k], len_lpc[k], c->sB)) { c->err = "LPC3 launch failed"; return 1; }
+    if (new_event(&ev_lpc[k])) return 1;
+    HIPCK(c, hipEventRecord(ev_lpc[k], c->sB));
+    return 0;
+  };
+  if (lpc_chunk(0) || lpc_chunk(1)) return 1;
   hipStream_t last_stream = c->sB;
   for (int k = 0; k < nchunk; k++) {
+    HIPCK(c, hipStreamWaitEvent(sLead, ev_lpc[k], 0));
     hipEvent_t a = nullptr, b = nullptr, e1;
     const bool dominant = pd.lms[0].S != 1280 || sacopt_lms_variant(pd.lms[0].S, pd.lms[0].D, n_lms[0][k], c->bits);
     if (dominant) {
@@ -785,8 +815,10 @@ static int final_pass_enqueue(sacopt_ctx *c, const ProfDesc &pd, const std::vect
         HIPCK(c, hipEventRecord(e2, c->sB));
         HIPCK(c, hipStreamWaitEvent(c->sD, e2, 0));
         fs = c->sD;
+        if (lpc_chunk(k + 2)) return 1;
       }
     }
+    if (!c->sD && lpc_chunk(k + 2)) return 1;
     if (sacopt_launch_mix(pd.nlms, d_mix[k], n_mix[k], fs)) { c->err = "k_mix launch failed"; return 1; }
     last_stream = fs;
   }
