@@ -321,6 +321,9 @@ static int upload(sacopt_ctx *c, const std::vector<T> &h, T **d) {
 static int begin_call(sacopt_ctx *c) {
   HIPCK(c, hipSetDevice(c->device));
   c->err.clear();
+  // a call that failed half-way may have left work in flight on the pipeline streams; the arena is about to be reused
+  for (hipStream_t s : {c->st, c->sA, c->sAall, c->sB, c->sC, c->sD})
+    if (s) HIPCK(c, hipStreamSynchronize(s));
   for (auto &p : c->lms_ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   c->lms_ev.clear();
   for (hipEvent_t e : c->pipe_ev) (void)hipEventDestroy(e);

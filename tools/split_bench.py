@@ -1,0 +1,19 @@
+"""Optimize-only and final-pass-only times of the bench workload (what bounds sacopt_encode_frames)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from sac_amd import sacopt
+from sac_amd.synth import stereo_clip
+FRAME, NF = 176400, 15
+L, R = stereo_clip(1000, NF * FRAME)
+dL = torch.from_numpy(L).cuda(); dR = torch.from_numpy(R).cuda()
+outb = [torch.empty_like(dL) for _ in range(4)]
+frames = [(dL.data_ptr() + 4 * f * FRAME, dR.data_ptr() + 4 * f * FRAME, FRAME) for f in range(NF)]
+outs = [dict(e0=outb[0].data_ptr() + 4 * f * FRAME, e1=outb[1].data_ptr() + 4 * f * FRAME,
+             u0=outb[2].data_ptr() + 4 * f * FRAME, u1=outb[3].data_ptr() + 4 * f * FRAME) for f in range(NF)]
+ctx = sacopt.Context(0)
+for name, fn in (("optimize", lambda: ctx.optimize(2, frames)), ("predict", lambda: ctx.predict(2, frames, device_out=outs)),
+                 ("encode", lambda: ctx.encode(2, frames, device_out=outs))):
+    fn(); torch.cuda.synchronize()
+    t = time.perf_counter(); fn(); fn(); torch.cuda.synchronize()
+    print(f"{name:9s} {(time.perf_counter() - t) * 500:8.1f} ms")
