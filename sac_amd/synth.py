@@ -104,3 +104,17 @@ def stereo_clip(seed: int, n: int, rate: int = 44100, bits: int = 16):
     np.clip(L, -lim - 1, lim, out=L)
     np.clip(R, -lim - 1, lim, out=R)
     return L.astype(np.int32), R.astype(np.int32)
+
+
+def degenerate_clips(n=3000):
+    """Inputs that stress the OLS stage (rank-deficient covariance, "matrix indefinit" handling) and the
+    adaptive stages (constant, periodic, sparse): name -> (L, R), integer-deterministic."""
+    t = np.arange(n, dtype=np.int64)
+    tri = np.abs((t * 37) % 2048 - 1024) * 12 - 6000          # integer triangle wave
+    return {
+        "dc": (np.full(n, 1000, np.int32), np.full(n, -700, np.int32)),
+        "tri": (tri.astype(np.int32), np.roll(tri, 5).astype(np.int32)),
+        "ramp": ((t % 64 * 100).astype(np.int32), (t % 32 * 50).astype(np.int32)),
+        "impulse": (np.where(t % 500 == 0, 30000, 0).astype(np.int32), np.where(t % 333 == 0, -30000, 0).astype(np.int32)),
+        "wide24": (((t * 7919) % 16000000 - 8000000).astype(np.int32), ((t * 104729) % 9000000 - 4500000).astype(np.int32)),
+    }

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from sac_amd import sacopt
-from sac_amd.synth import stereo_clip
+from sac_amd.synth import stereo_clip, degenerate_clips
 
 pytestmark = pytest.mark.gpu
 
@@ -212,3 +212,24 @@ def test_predict_many_frames_kernel_variants(ctx, oracle):
     # identical inputs give identical outputs wherever they sit in the batch
     for i in range(7, 98, 7):
         assert np.array_equal(outs[i]["e0"][:16500], outs[0]["e0"][:16500])
+
+
+def test_degenerate_inputs_vs_oracle(ctx, oracle):
+    # constant / periodic / sparse / 24-bit inputs (see sac_amd.synth.degenerate_clips)
+    clips = degenerate_clips(2500)
+    for prof in (0, 1, 2):
+        outs = ctx.predict(prof, list(clips.values()), maps=True)
+        for (name, (L, R)), o in zip(clips.items(), outs):
+            ref = oracle.predict(prof, L, R, maps=True)
+            for k in ("e0", "e1", "u0", "u1", "m0", "m1", "maxbpn"):
+                assert np.array_equal(o[k], ref[k]), (name, prof, k)
+
+
+def test_optimize_small_budget_vs_oracle(ctx, oracle):
+    # BASELINE configs[1]: "small candidate budget" = coefficient 0 only (baseline + 10 GetCost calls)
+    frames = [stereo_clip(80, 4096), stereo_clip(81, 3333)]
+    best, traces, rows = ctx.optimize(2, frames, ncoef_loop=1)
+    assert list(rows) == [11, 11]
+    for f, (L, R) in enumerate(frames):
+        ob, ot = oracle.optimize(2, L, R, ncoef_loop=1)
+        assert same_bits(best[f], ob) and same_bits(traces[f], ot), f

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from oracle_lib import Oracle, Ref, have_ref
-from sac_amd.synth import stereo_clip
+from sac_amd.synth import stereo_clip, degenerate_clips
 
 pytestmark = pytest.mark.skipif(not have_ref(), reason="oracle/_ref not built (needs /root/reference)")
 
@@ -92,3 +92,14 @@ def test_frame_record_bytes_from_oracle_residuals(pair):
     for prof in (0, 1, 2):
         res = o.predict(prof, L, R, maps=True)
         assert oracle_lib.ref_encode_residuals(r, prof, L, R, res) == oracle_lib.ref_encode_frame(r, prof, L, R), prof
+
+
+def test_degenerate_inputs(pair):
+    # constant / periodic / sparse / 24-bit inputs: rank-deficient covariance, Cholesky failures keep the
+    # previous solution (lpc.h:216-218), large Golomb means
+    o, r = pair
+    for name, (L, R) in degenerate_clips(2500).items():
+        for prof in (0, 1, 2):
+            a = o.predict(prof, L, R, maps=True); b = r.predict(prof, L, R, maps=True)
+            for k in a:
+                assert np.array_equal(a[k], b[k]), (name, prof, k)
