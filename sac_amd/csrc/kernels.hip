@@ -115,6 +115,23 @@ __device__ __forceinline__ double mfma_pass30(uint32_t addr, double acc) {
 }
 #undef MF
 
+// Lane i of every 16-lane row receives the value of lane i-O of the same row (0. for i < O): DPP row_shr.
+template <int O>
+__device__ __forceinline__ double row_shr(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x110 + O, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x110 + O, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// Inclusive prefix sum over each 16-lane row (tree order: only ever used as a guess)
+__device__ __forceinline__ double row_prefix16(double v) {
+  v += row_shr<1>(v);
+  v += row_shr<2>(v);
+  v += row_shr<4>(v);
+  v += row_shr<8>(v);
+  return v;
+}
+
 // ulp of a normal double as a power of two (0 for zero / tiny values: no candidates then)
 __device__ __forceinline__ double ulp_pow2(double x, double *inv) {
   const int e = (__double2hiint(x) >> 20) & 0x7ff;
@@ -248,9 +265,7 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
       if (sm == 0) {  // P0: segment sums from zero -> guesses of the segment inputs
         const double a = mfma_pass30(paddr, 0.);
         gA = __shfl(a, dl);  // lane l now holds A_(l&15)
-        double sh = gA;      // exclusive prefix over the 16 segments (any order: only a guess)
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) { const double v = __shfl_up(sh, o, 16); if (j16 >= o) sh += v; }
+        double sh = row_prefix16(gA);  // prefix over the 16 segments (any order: only a guess)
         sh -= gA;  // inclusive -> exclusive (exact for j = 1: A_0 + A_1 - A_1 may round, so fix it up)
         const double a0 = bcast(gA, 0);
         if (j16 == 1) sh = a0;
@@ -500,9 +515,7 @@ __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs
     if (wave < 4) {
       // guess: every segment summed from +0 (exact for segment 0), prefix in any order
       const double A = __shfl(mfma_pass30(paddr, 0.), dl);
-      double sh = A;
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) { const double v = __shfl_up(sh, o, 16); if (jA >= o) sh += v; }
+      double sh = row_prefix16(A);
       sh -= A;
       const double a0 = bcast(A, 0);
       if (jA == 1) sh = a0;  // x_1 is known exactly
