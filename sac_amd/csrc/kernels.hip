@@ -567,8 +567,8 @@ __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs
         if (n > 0) x = bB + (double)dv * bU;
         // ---- P2: verify every boundary
         const double xs = __shfl(x, 4 * jD);
-        res = mfma_pass30(paddr, xs);
         const double xn = __shfl(x, 4 * (jD < 15 ? jD + 1 : 15));
+        res = mfma_pass30(paddr, xs);
         const bool bad = (jD < 15) && (__double_as_longlong(res) != __double_as_longlong(xn));
         const unsigned long long mask = __ballot(bad);
         rounds++;
