@@ -6,7 +6,9 @@
 //   PredictStereoFrame(profile,0,1,from,n) src/codec.cpp:154-214
 //   GetCost(profile,coef,testval,start,n)  src/codec.cpp:341-352  (CostGolomb state carried, :364)
 //   Optimize(profile)                      src/codec.cpp:354-408
-// Buffers are the reference's public members (samples / error / s2u_error, src/codec.h:29-31).
+// Buffers are the reference's public members (samples / error / s2u_error / s2u_error_map, src/codec.h:29-31);
+// maxbpn / maxbpn_map stand for framestats[ch].maxbpn{,_map} (src/codec.h:49, src/codec.cpp:207-211).
+// PredictBatch is the batched form a throughput-minded Codec::EncodeFile would call.
 // Header-only; link with libsacopt.so. Not thread-safe (like the reference).
 #ifndef SACOPT_FRAMECODER_H
 #define SACOPT_FRAMECODER_H
@@ -37,16 +39,47 @@ class FrameCoder {
     baseprofile.coefs.resize(n);
     for (int i = 0; i < n; i++) baseprofile.coefs[i] = {tab[3 * i], tab[3 * i + 1], tab[3 * i + 2]};
     optprofile = baseprofile;
-    for (auto *v : {&samples, &error, &s2u_error}) { v->resize(2); for (auto &c : *v) c.resize(framesz); }
-    maxbpn[0] = maxbpn[1] = 0;
+    for (auto *v : {&samples, &error, &s2u_error, &s2u_error_map}) { v->resize(2); for (auto &c : *v) c.resize(framesz); }
+    maxbpn[0] = maxbpn[1] = maxbpn_map[0] = maxbpn_map[1] = 0;
   }
   void SetNumSamples(int nsamples) { numsamples = nsamples; }
   int GetNumSamples() const { return numsamples; }
 
   // FrameCoder::Predict with the optimizer call of codec.cpp:455-456 enabled on request.
+  // One library call: the optimizer rounds and the full-frame pass overlap on the GPU.
   void Predict(bool optimize = false) {
-    if (optimize) { optprofile = baseprofile; Optimize(optprofile); }
-    PredictStereoFrame(baseprofile, 0, 1, 0, numsamples);  // "ref+opt": the stream uses baseprofile (codec.cpp:459)
+    FrameCoder *self = this;
+    PredictBatch(&self, 1, optimize);
+  }
+
+  // Predict() for a batch of frames (same profile type) in one call; frames are independent (codec.cpp:156-159).
+  static void PredictBatch(FrameCoder *const *fc, int nframes, bool optimize) {
+    if (nframes <= 0) return;
+    FrameCoder &f0 = *fc[0];
+    const int ncoef = (int)f0.baseprofile.coefs.size();
+    std::vector<sacopt_frame> fr(nframes);
+    std::vector<sacopt_residuals> out(nframes);
+    std::vector<double> prof(3 * ncoef), best((size_t)nframes * ncoef);
+    for (int i = 0; i < ncoef; i++) { prof[3 * i] = f0.baseprofile.coefs[i].vmin; prof[3 * i + 1] = f0.baseprofile.coefs[i].vmax; prof[3 * i + 2] = f0.baseprofile.coefs[i].vdef; }
+    for (int b = 0; b < nframes; b++) {
+      FrameCoder &f = *fc[b];
+      if (f.baseprofile.type != f0.baseprofile.type) throw std::invalid_argument("mixed profiles in one batch");
+      fr[b] = {f.samples[0].data(), f.samples[1].data(), f.numsamples};
+      out[b] = sacopt_residuals();
+      out[b].err0 = f.error[0].data(); out[b].err1 = f.error[1].data();
+      out[b].s2u0 = f.s2u_error[0].data(); out[b].s2u1 = f.s2u_error[1].data();
+      out[b].map0 = f.s2u_error_map[0].data(); out[b].map1 = f.s2u_error_map[1].data();
+    }
+    f0.check(sacopt_encode_frames(f0.ctx_, f0.baseprofile.type, nframes, fr.data(), prof.data(), optimize ? ncoef : 0, best.data(), out.data()));
+    for (int b = 0; b < nframes; b++) {
+      FrameCoder &f = *fc[b];
+      f.maxbpn[0] = out[b].maxbpn[0]; f.maxbpn[1] = out[b].maxbpn[1];
+      f.maxbpn_map[0] = out[b].maxbpn[2]; f.maxbpn_map[1] = out[b].maxbpn[3];
+      if (optimize) {
+        f.optprofile = f.baseprofile;
+        for (int i = 0; i < ncoef; i++) f.optprofile.coefs[i].vdef = best[(size_t)b * ncoef + i];
+      }
+    }
   }
 
   void PredictStereoFrame(const SacProfile &profile, int ch0, int ch1, int from, int n) {
@@ -55,11 +88,13 @@ class FrameCoder {
     sacopt_residuals out = {};
     out.err0 = error[0].data(); out.err1 = error[1].data();
     out.s2u0 = s2u_error[0].data(); out.s2u1 = s2u_error[1].data();
+    out.map0 = s2u_error_map[0].data(); out.map1 = s2u_error_map[1].data();
     std::vector<double> c(profile.coefs.size());
     for (size_t i = 0; i < c.size(); i++) c[i] = profile.coefs[i].vdef;
     const int32_t f = from, nn = n;
     check(sacopt_predict_stereo_frames(ctx_, profile.type, 1, &fr, &f, &nn, c.data(), &out));
     maxbpn[0] = out.maxbpn[0]; maxbpn[1] = out.maxbpn[1];
+    maxbpn_map[0] = out.maxbpn[2]; maxbpn_map[1] = out.maxbpn[3];
   }
 
   double GetCost(SacProfile &profile, int coef, double testval, int start_sample, int samples_to_optimize) {
@@ -82,8 +117,8 @@ class FrameCoder {
     for (size_t i = 0; i < best.size(); i++) profile.coefs[i].vdef = best[i];
   }
 
-  std::vector<std::vector<int32_t>> samples, error, s2u_error;
-  int maxbpn[2];
+  std::vector<std::vector<int32_t>> samples, error, s2u_error, s2u_error_map;
+  int maxbpn[2], maxbpn_map[2];
   SacProfile baseprofile, optprofile;
 
  private:

@@ -233,3 +233,56 @@ def test_optimize_small_budget_vs_oracle(ctx, oracle):
     for f, (L, R) in enumerate(frames):
         ob, ot = oracle.optimize(2, L, R, ncoef_loop=1)
         assert same_bits(best[f], ob) and same_bits(traces[f], ot), f
+
+
+# ---------------------------------------------------------------- C++ host side (sac_amd/host/framecoder.h)
+def _host_example_fill(n, seed):
+    # same integer generator as sac_amd/host/host_example.cpp::fill
+    s = (seed * 2654435761 + 12345) & 0xffffffff
+    l = np.zeros(n, np.int32); r = np.zeros(n, np.int32)
+    a = 0
+    for i in range(n):
+        s = (s * 1664525 + 1013904223) & 0xffffffff
+        noise = ((s >> 16) & 0x3ff) - 512
+        a += 37 if (i // 64) & 1 else -37
+        t = a * 3
+        b = (abs(t) // 4) * (1 if t >= 0 else -1) + (abs(noise) // 4) * (1 if noise >= 0 else -1)   # C division truncates
+        l[i] = a * 8 + noise
+        r[i] = b * 8 - (abs(noise) // 2) * (1 if noise >= 0 else -1)
+    return l, r
+
+
+def _fnv(a):
+    h = 1469598103934665603
+    for v in np.ascontiguousarray(a, dtype=np.int32).view(np.uint32).tolist():
+        h = ((h ^ v) * 1099511628211) & 0xffffffffffffffff
+    return h
+
+
+def test_cpp_host_framecoder():
+    # the C++ mirror of FrameCoder (PredictBatch -> sacopt_encode_frames) run as its own program must give
+    # what the ctypes path gives: residual / s2u / map checksums, maxbpn, selected parameters
+    import os, subprocess
+    exe = os.path.join(os.path.dirname(sacopt.LIB_PATH), "host", "host_example")
+    if not os.path.exists(exe):
+        pytest.skip("host_example not built")
+    n, nframes = 3000, 2
+    out = subprocess.run([exe, "2", str(nframes), str(n), "1"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    lines = [ln.split() for ln in out.stdout.strip().splitlines()]
+    assert len(lines) == nframes
+    c = sacopt.Context(0)
+    try:
+        frames = [_host_example_fill(n, 100 + b) for b in range(nframes)]
+        best, outs = c.encode(2, frames, maps=True)
+    finally:
+        c.close()
+    for b, ln in enumerate(lines):
+        L, R = frames[b]
+        o = outs[b]
+        assert [int(x, 16) for x in ln[3:5]] == [_fnv(L), _fnv(R)], "generator mismatch"
+        assert [int(x, 16) for x in ln[6:8]] == [_fnv(o["e0"]), _fnv(o["e1"])]
+        assert [int(x, 16) for x in ln[9:11]] == [_fnv(o["u0"]), _fnv(o["u1"])]
+        assert [int(x, 16) for x in ln[12:14]] == [_fnv(o["m0"]), _fnv(o["m1"])]
+        assert [int(x) for x in ln[15:19]] == list(o["maxbpn"])
+        assert same_bits(np.array([float(x) for x in ln[20:28]]), best[b])
