@@ -154,7 +154,7 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
   constexpr int T = S + D, T4 = T / 4, M = RL - 1, CH = LMS_CHUNK;
   // SPEC: 16 segments of 120 products, padded to a stride of 122 doubles so that the 16 segment
   // lanes of a ds_read_b64 half fall on 16 different 4-bank groups (stride 120 -> 4-way conflict)
-  constexpr int SEG = 120, SEGP = 122, TP = SPEC ? 16 * SEGP : T;
+  constexpr int SEG = 120, SEGP = 122, TP = SPEC ? 16 * SEGP : T + 4;  // T + 4: the two channels' MFMA operands on different banks
   static_assert(T % 4 == 0, "tap count must be a multiple of 4");
   static_assert(RL >= CH + (S > D ? S : D) + 1, "ring too short");
   static_assert(NT * R >= 2 * T, "not enough tap slots");
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
     else { const int j = i - S; src = 1 - c; lag = (c == 0 ? 1 : 0) + j; mu[r] = job.mu2; }
     hsel[r] = src;
     hoff[r] = (-lag) & M;
-    paddr[r] = SPEC ? c * TP + (i / SEG) * SEGP + (i % SEG) : c * T + i;
+    paddr[r] = SPEC ? c * TP + (i / SEG) * SEGP + (i % SEG) : c * TP + i;
     w[r] = 0.; eg[r] = 0.;
     if (!valid[r]) { hsel[r] = 0; hoff[r] = 0; paddr[r] = 0; }
     if (t0 > 0 && job.state) {  // resume: weights / gradient energies of the previous chunk
