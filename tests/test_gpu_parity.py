@@ -286,3 +286,35 @@ def test_cpp_host_framecoder():
         assert [int(x, 16) for x in ln[12:14]] == [_fnv(o["m0"]), _fnv(o["m1"])]
         assert [int(x) for x in ln[15:19]] == list(o["maxbpn"])
         assert same_bits(np.array([float(x) for x in ln[20:28]]), best[b])
+
+
+# ---------------------------------------------------------------- BASELINE sizes (176400-sample frames)
+def test_full_size_frames_properties(ctx, oracle):
+    # Size-independent properties at the benchmark's frame size (4 s @ 44.1 kHz):
+    #  * causality: the residuals of a prefix do not depend on what follows (prefix run == head of the full run),
+    #    which also crosses different chunkings of the pipeline;
+    #  * FrameCoder::Predict with Optimize == Optimize and PredictStereoFrame run separately;
+    #  * the baseline row of the Optimize trace is GetCost(base profile) on the centre window (codec.cpp:356-386);
+    #  * one full frame against the oracle (a few seconds of CPU).
+    n = 176400
+    frames = [stereo_clip(300, n), stereo_clip(301, n)]
+    best_e, outs = ctx.encode(2, frames, maps=True)
+    full = ctx.predict(2, frames, maps=True)
+    for a, b in zip(outs, full):
+        for k in ("e0", "e1", "u0", "u1", "m0", "m1", "maxbpn"):
+            assert np.array_equal(a[k], b[k]), k
+    cut = 100000
+    head = ctx.predict(2, [(L[:cut], R[:cut]) for L, R in frames])
+    for h, f in zip(head, full):
+        assert np.array_equal(h["e0"], f["e0"][:cut]) and np.array_equal(h["e1"], f["e1"][:cut])
+    best_o, traces, rows = ctx.optimize(2, frames)
+    assert same_bits(best_o, best_e) and list(rows) == [84, 84]
+    base = sacopt.base_profile(2)[:, 2]
+    wn = n // 8; frm = (n - wn) // 2
+    costs, _ = ctx.get_costs(2, frames, np.tile(base, (2, 1, 1)), frm=[frm, frm], n=[wn, wn])
+    for f in range(2):
+        assert traces[f][0][0] == -1 and same_bits(traces[f][0][2:3], costs[f])
+    L, R = frames[0]
+    ref = oracle.predict(2, L, R, maps=True)
+    for k in ("e0", "e1", "u0", "u1", "m0", "m1", "maxbpn"):
+        assert np.array_equal(full[0][k], ref[k]), k
