@@ -432,7 +432,8 @@ __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs
   __shared__ double ringo[L1_RLO];  // own channel's stage inputs   (taps 0..1279: lags 1..1280)
   __shared__ double ringx[L1_RLX];  // other channel's stage inputs (taps 1280..1919)
   __shared__ double pbuf[CH];
-  __shared__ double sOut[16][4];
+  __shared__ double sOut[16][16];
+  __shared__ int sJ[4][16][16];
   __shared__ double predv;
   __shared__ float tab[RSQ_LDS_MAX];
 
@@ -510,7 +511,9 @@ __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs
       if (valid[r]) prods[pa[r]] = w[r] * h[r];
     }
     __syncthreads();
-    // ---- P1: exact segment sums from the candidate inputs g_j + (m-2) ulp
+    // ---- P1: exact segment sums from the 16 candidate inputs g_j + (m-8) ulp. The four columns of the 4x4
+    // MFMA output share their A terms (B == 1) but keep their own C, so one wave sums every segment from four
+    // different inputs at once: wave w, column c -> candidate 4w + c.
     double gBase = 0., gU = 0., gIU = 0.;  // lane l: boundary (l & 15)
     if (wave < 4) {
       // guess: every segment summed from +0 (exact for segment 0), prefix in any order
@@ -521,10 +524,10 @@ __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs
       if (jA == 1) sh = a0;  // x_1 is known exactly
       if (jA == 0) sh = 0.;
       gU = ulp_pow2(sh, &gIU);
-      gBase = sh - 2. * gU;
-      const double stv = __shfl(gBase, jD) + (double)wave * __shfl(gU, jD);
-      const double o = mfma_pass30(paddr, stv);
-      if ((lane & 3) == 0) sOut[jD][wave] = o;
+      gBase = sh - 8. * gU;
+      const int m16 = 4 * wave + (lane & 3);
+      const double stv = __shfl(gBase, jD) + (double)m16 * __shfl(gU, jD);
+      sOut[jD][m16] = mfma_pass30(paddr, stv);
     }
     __syncthreads();
     // ---- walk + P2 (wave 0)
@@ -533,22 +536,34 @@ __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs
       const double bB = __shfl(gBase, tj), bU = __shfl(gU, tj);
       const int nb = tj < 15 ? tj + 1 : 15;
       const double nB = __shfl(gBase, nb), nIU = __shfl(gIU, nb);
-      // J[k] at lane (tj, tm): offset at boundary tj + 2^k if the offset at boundary tj is tm
-      int J[4];
-      J[0] = (tj < 15) ? (int)((sOut[tj][tm] - nB) * nIU) : 0;
+      // sJ[k][j][m]: offset at boundary j + 2^k if the offset at boundary j is m (0..15); lane (tj, tm) builds
+      // the entries m = tm + 4c. One wave: LDS operations of a wave complete in program order.
+      int Jc[4];
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        Jc[c] = (tj < 15) ? (int)((sOut[tj][tm + 4 * c] - nB) * nIU) : 0;
+        sJ[0][tj][tm + 4 * c] = Jc[c];
+      }
+      __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int k = 0; k < 3; k++) {
         const int p = (tj + (1 << k)) < 15 ? tj + (1 << k) : 15, tg = (tj + (2 << k)) < 15 ? tj + (2 << k) : 15;
         const int ea = __shfl(ex, p), eb = __shfl(ex, tg);
-        const int dv = J[k], mm = dv & 3;
-        const int f = __shfl(J[k], 4 * p + mm);
-        J[k + 1] = f + ulp_shift(dv - mm, ea, eb);
+        int f[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) f[c] = sJ[k][p][Jc[c] & 15];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          Jc[c] = f[c] + ulp_shift(Jc[c] - (Jc[c] & 15), ea, eb);
+          sJ[k + 1][tj][tm + 4 * c] = Jc[c];
+        }
+        __builtin_amdgcn_wave_barrier();
       }
       double x = 0.;  // lane group tj: walked input of segment tj (x_0 = +0 exactly)
       const double x1 = sOut[0][0];  // segment 0 summed from +0: exact
       if (tj == 1) x = x1;
       int sp = 1;                                         // boundaries <= sp are exact
-      int sd = __builtin_amdgcn_readlane(J[0], 0);        // offset of x_sp on boundary sp's grid
+      int sd = sJ[0][0][0];                               // offset of x_sp on boundary sp's grid
       double res = 0.;
       for (int guard = 0; guard < 17; guard++) {
         // ---- evaluate the boundaries after sp: binary decomposition of the distance
@@ -559,8 +574,8 @@ __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs
           const bool take = n > 0 && ((n >> k) & 1);
           const int pn = (p + (1 << k)) < 15 ? p + (1 << k) : 15;
           const int ea = __shfl(ex, p), eb = __shfl(ex, pn);
-          const int mm = dv & 3;
-          const int f = __shfl(J[k], 4 * p + mm);
+          const int mm = dv & 15;
+          const int f = sJ[k][p][mm];
           const int dn = f + ulp_shift(dv - mm, ea, eb);
           if (take) { dv = dn; p = pn; }
         }
