@@ -432,8 +432,8 @@ __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs
   __shared__ double ringo[L1_RLO];  // own channel's stage inputs   (taps 0..1279: lags 1..1280)
   __shared__ double ringx[L1_RLX];  // other channel's stage inputs (taps 1280..1919)
   __shared__ double pbuf[CH];
-  __shared__ double sOut[16][16];
   __shared__ int sJ[4][16][16];
+  __shared__ double sX1;
   __shared__ double predv;
   __shared__ float tab[RSQ_LDS_MAX];
 
@@ -527,24 +527,24 @@ __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs
       gBase = sh - 8. * gU;
       const int m16 = 4 * wave + (lane & 3);
       const double stv = __shfl(gBase, jD) + (double)m16 * __shfl(gU, jD);
-      sOut[jD][m16] = mfma_pass30(paddr, stv);
+      const int nbD = jD < 15 ? jD + 1 : 15;
+      const double nB = __shfl(gBase, nbD), nIU = __shfl(gIU, nbD);
+      const double o = mfma_pass30(paddr, stv);
+      // table entry: offset on the next boundary's grid of this segment's output
+      sJ[0][jD][m16] = (jD < 15) ? (int)((o - nB) * nIU) : 0;
+      if (jD == 0 && m16 == 0) sX1 = o;  // segment 0 summed from +0: x_1, exact
     }
     __syncthreads();
     // ---- walk + P2 (wave 0)
     if (wave == 0) {
       const int ex = (__double2hiint(gU) >> 20) & 0x7ff;  // lane l: exponent field of the ulp at boundary l & 15 (0: no grid)
       const double bB = __shfl(gBase, tj), bU = __shfl(gU, tj);
-      const int nb = tj < 15 ? tj + 1 : 15;
-      const double nB = __shfl(gBase, nb), nIU = __shfl(gIU, nb);
-      // sJ[k][j][m]: offset at boundary j + 2^k if the offset at boundary j is m (0..15); lane (tj, tm) builds
-      // the entries m = tm + 4c. One wave: LDS operations of a wave complete in program order.
+      // sJ[k][j][m]: offset at boundary j + 2^k if the offset at boundary j is m (0..15); sJ[0] comes from the
+      // P1 waves, lane (tj, tm) builds the entries m = tm + 4c of the others. One wave: its LDS operations
+      // complete in program order.
       int Jc[4];
 #pragma unroll
-      for (int c = 0; c < 4; c++) {
-        Jc[c] = (tj < 15) ? (int)((sOut[tj][tm + 4 * c] - nB) * nIU) : 0;
-        sJ[0][tj][tm + 4 * c] = Jc[c];
-      }
-      __builtin_amdgcn_wave_barrier();
+      for (int c = 0; c < 4; c++) Jc[c] = sJ[0][tj][tm + 4 * c];
 #pragma unroll
       for (int k = 0; k < 3; k++) {
         const int p = (tj + (1 << k)) < 15 ? tj + (1 << k) : 15, tg = (tj + (2 << k)) < 15 ? tj + (2 << k) : 15;
@@ -560,24 +560,29 @@ __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs
         __builtin_amdgcn_wave_barrier();
       }
       double x = 0.;  // lane group tj: walked input of segment tj (x_0 = +0 exactly)
-      const double x1 = sOut[0][0];  // segment 0 summed from +0: exact
-      if (tj == 1) x = x1;
+      if (tj == 1) x = sX1;
       int sp = 1;                                         // boundaries <= sp are exact
       int sd = sJ[0][0][0];                               // offset of x_sp on boundary sp's grid
       double res = 0.;
       for (int guard = 0; guard < 17; guard++) {
         // ---- evaluate the boundaries after sp: binary decomposition of the distance
         const int n = tj - sp;
-        int p = sp, dv = sd;
+        int pk[5], ek[5];  // positions visited (they depend on the distance only) and their grid exponents
+        pk[4] = sp;
 #pragma unroll
         for (int k = 3; k >= 0; k--) {
           const bool take = n > 0 && ((n >> k) & 1);
-          const int pn = (p + (1 << k)) < 15 ? p + (1 << k) : 15;
-          const int ea = __shfl(ex, p), eb = __shfl(ex, pn);
+          const int pn = (pk[k + 1] + (1 << k)) < 15 ? pk[k + 1] + (1 << k) : 15;
+          pk[k] = take ? pn : pk[k + 1];
+        }
+#pragma unroll
+        for (int k = 0; k < 5; k++) ek[k] = __shfl(ex, pk[k]);
+        int dv = sd;
+#pragma unroll
+        for (int k = 3; k >= 0; k--) {
           const int mm = dv & 15;
-          const int f = sJ[k][p][mm];
-          const int dn = f + ulp_shift(dv - mm, ea, eb);
-          if (take) { dv = dn; p = pn; }
+          const int f = sJ[k][pk[k + 1]][mm];
+          if (pk[k] != pk[k + 1]) dv = f + ulp_shift(dv - mm, ek[k + 1], ek[k]);
         }
         if (n > 0) x = bB + (double)dv * bU;
         // ---- P2: verify every boundary
