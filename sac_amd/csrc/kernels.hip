@@ -140,6 +140,131 @@ __device__ __forceinline__ double ulp_pow2(double x, double *inv) {
   return __hiloint2double((e - 52) << 20, 0);           // 2^(e-1023-52)
 }
 
+__device__ __forceinline__ int ulp_shift(int v, int ea, int eb) {  // offset in ulps 2^ea -> ulps 2^eb (guess only)
+  int ks = (ea && eb) ? ea - eb : 0;
+  ks = ks > 31 ? 31 : (ks < -31 ? -31 : ks);
+  return ks >= 0 ? (int)((uint32_t)v << ks) : ((v + (1 << (-ks - 1))) >> (-ks));  // to nearest: the likelier of the two outcomes
+}
+
+// ------------------------------------------------------------------------------------------
+// Speculative exact summation of one 1920-term chain (16 segments x 120 products in LDS, segment
+// stride 122 doubles starting at LDS byte address prods_addr). Called by every wave of the workgroup
+// (it contains a workgroup barrier); `group` in 0..3 marks the four waves that sum candidates for this
+// chain, -1 the bystanders; `walker` is the one candidate wave (group 0) that follows the chain and
+// verifies it. Returns, in lane 60 of the walker, the strict left-to-right FP64 sum (nlms.h:110-111).
+//   P1    each candidate wave: every segment summed from +0 (30-step MFMA pass, 16 chains) -- the prefix
+//         of these sums guesses the segment inputs g_j -- then every segment summed EXACTLY from 16
+//         candidate inputs g_j + (m-8) ulp: the four columns of the 4x4 MFMA output share their A terms
+//         (B == 1) but keep their own C, so wave w, column c carries candidate 4w + c. Each output is
+//         stored as its offset on the next boundary's candidate grid: sJ[0][j][m].
+//   walk  sJ[k][j][m] (offset at boundary j + 2^k given offset m at j) by doubling, 3 rounds; then every
+//         boundary's offset from the exact x_1 by binary decomposition of its distance, 4 lookups.
+//         Offsets outside 0..15 are extended periodically (shift by 16q ulps, converted between binade
+//         grids): a guess, but a good one -- shifts by high powers of two survive the coarser binades a
+//         segment's partial sums pass through (4 candidates / shifts by 4q failed on 30-45 % of the
+//         samples, 16 fail on 5-12 %).
+//   P2    every segment re-summed exactly from its walked input; each output must EQUAL the next walked
+//         input bit for bit. By induction from x_0 = +0 the last output then IS the sequential sum. A
+//         mismatch pins the first wrong boundary to the exact value just computed and re-evaluates the
+//         later ones (each round fixes at least one boundary).
+// Everything before P2 only affects speed; exactness rests on P2 alone.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double spec_exact_sum(uint32_t prods_addr, int (*sJ)[16][16], double *sX1, int group, bool walker,
+                                                 int dbg, long long &rounds) {
+  constexpr int SEGP = 122;
+  const int lane = threadIdx.x & 63;
+  const int jA = lane & 15, kA = lane >> 4;                      // A-operand lane: chain jA, term 4s+kA at step s
+  const int jD = 4 * ((lane >> 2) & 3) + (lane >> 4);             // chain held by this D-layout lane
+  const int dl = 16 * (lane & 3) + 4 * ((lane >> 2) & 3);         // D-layout lane of chain (lane & 15)
+  const int tj = lane >> 2, tm = lane & 3;                        // walk layout: boundary tj, table entries tm + 4c
+  const uint32_t paddr = prods_addr + (uint32_t)(jA * SEGP + kA) * 8u;
+  double gBase = 0., gU = 0., gIU = 0.;  // lane l: boundary (l & 15)
+  if (group >= 0) {
+    const double A = __shfl(mfma_pass30(paddr, 0.), dl);
+    double sh = row_prefix16(A);  // any order: only a guess
+    sh -= A;
+    const double a0 = bcast(A, 0);
+    if (jA == 1) sh = a0;  // x_1 is known exactly
+    if (jA == 0) sh = 0.;
+    gU = ulp_pow2(sh, &gIU);
+    gBase = sh - 8. * gU;
+    const int m16 = 4 * group + (lane & 3);
+    const double stv = __shfl(gBase, jD) + (double)m16 * __shfl(gU, jD);
+    const int nbD = jD < 15 ? jD + 1 : 15;
+    const double nB = __shfl(gBase, nbD), nIU = __shfl(gIU, nbD);
+    const double o = mfma_pass30(paddr, stv);
+    sJ[0][jD][m16] = (jD < 15) ? (int)((o - nB) * nIU) : 0;
+    if (jD == 0 && m16 == 0) *sX1 = o;  // segment 0 summed from +0: x_1, exact
+  }
+  __syncthreads();
+  double res = 0.;
+  if (walker) {
+    const int ex = (__double2hiint(gU) >> 20) & 0x7ff;  // lane l: exponent field of the ulp at boundary l & 15 (0: no grid)
+    const double bB = __shfl(gBase, tj), bU = __shfl(gU, tj);
+    // one wave: its LDS operations complete in program order
+    int Jc[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) Jc[c] = sJ[0][tj][tm + 4 * c];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const int p = (tj + (1 << k)) < 15 ? tj + (1 << k) : 15, tg = (tj + (2 << k)) < 15 ? tj + (2 << k) : 15;
+      const int ea = __shfl(ex, p), eb = __shfl(ex, tg);
+      int f[4];
+#pragma unroll
+      for (int c = 0; c < 4; c++) f[c] = sJ[k][p][Jc[c] & 15];
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        Jc[c] = f[c] + ulp_shift(Jc[c] - (Jc[c] & 15), ea, eb);
+        sJ[k + 1][tj][tm + 4 * c] = Jc[c];
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    double x = 0.;  // lane group tj: walked input of segment tj (x_0 = +0 exactly)
+    if (tj == 1) x = *sX1;
+    int sp = 1;              // boundaries <= sp are exact
+    int sd = sJ[0][0][0];    // offset of x_sp on boundary sp's grid
+    for (int guard = 0; guard < 17; guard++) {
+      // ---- offsets of the boundaries after sp: binary decomposition of the distance
+      const int n = tj - sp;
+      int pk[5], ek[5];  // positions visited (they depend on the distance only) and their grid exponents
+      pk[4] = sp;
+#pragma unroll
+      for (int k = 3; k >= 0; k--) {
+        const bool take = n > 0 && ((n >> k) & 1);
+        const int pn = (pk[k + 1] + (1 << k)) < 15 ? pk[k + 1] + (1 << k) : 15;
+        pk[k] = take ? pn : pk[k + 1];
+      }
+#pragma unroll
+      for (int k = 0; k < 5; k++) ek[k] = __shfl(ex, pk[k]);
+      int dv = sd;
+#pragma unroll
+      for (int k = 3; k >= 0; k--) {
+        const int mm = dv & 15;
+        const int f = sJ[k][pk[k + 1]][mm];
+        if (pk[k] != pk[k + 1]) dv = f + ulp_shift(dv - mm, ek[k + 1], ek[k]);
+      }
+      if (n > 0) x = bB + (double)dv * bU;
+      // ---- P2: verify every boundary
+      const double xs = __shfl(x, 4 * jD);
+      const double xn = __shfl(x, 4 * (jD < 15 ? jD + 1 : 15));
+      res = mfma_pass30(paddr, xs);
+      const bool bad = (jD < 15) && (__double_as_longlong(res) != __double_as_longlong(xn));
+      const unsigned long long mask = __ballot(bad);
+      rounds++;
+      if (mask == 0ull || (dbg & 16)) break;
+      int f = 0;  // first failing segment (D-layout lane of chain j: 16*(j&3) + 4*(j>>2))
+      while (f < 15 && !((mask >> (16 * (f & 3) + 4 * (f >> 2))) & 1ull)) f++;
+      f = __builtin_amdgcn_readfirstlane(f);
+      const double xt = bcast(res, 16 * (f & 3) + 4 * (f >> 2));  // exact x_{f+1}
+      if (tj == f + 1) x = xt;
+      sp = f + 1;
+      const double bq = bcast(gBase, f + 1), iq = bcast(gIU, f + 1);
+      sd = __builtin_amdgcn_readfirstlane((int)((xt - bq) * iq));
+    }
+  }
+  return res;  // chain 15 lives in D lanes 60..63
+}
+
 // ------------------------------------------------------------------------------------------
 // LMSADA2 stereo pair (src/pred/nlms.h:96-139), driven as StereoHigh/StereoNormal drive it
 // (src/profile.cpp:126-148,176-186):
@@ -165,8 +290,9 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
   // predictions of the current chunk; written to HBM once per chunk by all threads (a store per
   // sample would put an HBM write round trip in front of every barrier)
   __shared__ double pbuf[2][CH];
-  // speculative exact summation (SPEC): 16 segments x 4 candidate start values per channel
-  __shared__ double sBase[2][17], sU[2][17], sInvU[2][17], sOut[2][16][4];
+  // speculative exact summation (SPEC): boundary tables of spec_exact_sum, per channel
+  __shared__ int sJ[SPEC ? 2 : 1][4][16][16];
+  __shared__ double sX1[2];
   __shared__ float tab[RSQ_LDS_MAX];
 
   const LmsJob job = jobs[blockIdx.x];
@@ -244,95 +370,15 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
     __syncthreads();
     // ---- pred = 0.; for i: pred += w[i]*hist[i]  -- strict order, on the matrix pipe
     if constexpr (SPEC) {
-      // The 1920-term chain is cut into 16 segments of 120. A segment's exact output depends on
-      // its exact input, but the map input -> output is a shift for inputs on the same binade
-      // grid (and a staircase across binade rises), so: (P0) segment sums from 0 give guesses of
-      // the segment inputs; (P1) every segment is summed exactly from 4 candidate inputs around
-      // its guess; (walk) the true chain is followed through the tables (integer arithmetic in
-      // units of ulp, periodic extension outside a table); (P2) every segment is re-summed from
-      // the walked input and must reproduce the next walked input bit for bit -- by induction
-      // from x_0 = 0 the result then IS the sequential sum. A mismatch pins the first wrong
-      // boundary to the value P2 just computed and repeats (progress >= 1 segment per round).
-      static_assert(T == 1920 && NT >= 512, "SPEC is laid out for the (1280,640) stage, phases on waves 0..7");
-      // waves 0..7: channel = wave&1, candidate = wave>>1, so that the two channels' lead waves
-      // (0 and 1) and each channel's four candidate waves sit on different SIMDs
-      const int sc = wave & 1, sm = wave >> 1;
-      const int jA = lane & 15, kA = lane >> 4, jD = 4 * ((lane >> 2) & 3) + (lane >> 4);
-      const int dl = 16 * (lane & 3) + 4 * ((lane >> 2) & 3);  // D-layout lane of chain (lane & 15)
-      const uint32_t paddr = (uint32_t)(uintptr_t)&prods[sc][jA * SEGP + kA];
-      const int j16 = lane & 15;
-      double gA = 0., gBase = 0., gU = 0., gIU = 0.;  // lanes 0..15 (and their mod-16 copies): per-boundary values
-      if (sm == 0) {  // P0: segment sums from zero -> guesses of the segment inputs
-        const double a = mfma_pass30(paddr, 0.);
-        gA = __shfl(a, dl);  // lane l now holds A_(l&15)
-        double sh = row_prefix16(gA);  // prefix over the 16 segments (any order: only a guess)
-        sh -= gA;  // inclusive -> exclusive (exact for j = 1: A_0 + A_1 - A_1 may round, so fix it up)
-        const double a0 = bcast(gA, 0);
-        if (j16 == 1) sh = a0;
-        if (j16 == 0) sh = 0.;
-        gU = ulp_pow2(sh, &gIU);
-        gBase = sh - 2. * gU;
-        if (lane < 16) { sBase[sc][lane] = gBase; sU[sc][lane] = gU; sInvU[sc][lane] = gIU; }
-      }
-      __syncthreads();
-      if (sm < 4) {  // P1: exact segment sums from candidate inputs base + m*ulp
-        const double st = sBase[sc][jD] + (double)sm * sU[sc][jD];
-        sOut[sc][jD][sm] = mfma_pass30(paddr, st);
-      }
-      __syncthreads();
-      if (sm == 0) {
-        // table entry (j, m): next segment's offset (in its ulps) if segment j's input offset is m
-        const int tj = lane >> 2, tm = lane & 3;
-        int dv = 0, kl = 0, kr = 0;  // kl/kr: left/right shift converting segment tj's ulps into tj+1's
-        if (tj < 15) {
-          dv = (int)((sOut[sc][tj][tm] - sBase[sc][tj + 1]) * sInvU[sc][tj + 1]);
-          const int e0 = (__double2hiint(sU[sc][tj]) >> 20) & 0x7ff, e1 = (__double2hiint(sU[sc][tj + 1]) >> 20) & 0x7ff;
-          const int ks = (e0 && e1) ? e0 - e1 : 0;
-          kl = ks > 0 ? (ks < 31 ? ks : 31) : 0;
-          kr = ks < 0 ? (-ks < 31 ? -ks : 31) : 0;
-        }
-        int skl[15], skr[15];  // wave-uniform copies (scalar registers), fixed for this sample
-#pragma unroll
-        for (int j = 1; j < 15; j++) { skl[j] = __builtin_amdgcn_readlane(kl, 4 * j); skr[j] = __builtin_amdgcn_readlane(kr, 4 * j); }
-        const double a0 = bcast(gA, 0);
-        int first = 1;  // boundary from which the walk (re)starts
-        int del = __builtin_amdgcn_readfirstlane((bcast(gU, 1) != 0.) ? 2 : 0);  // x_1 = A_0 = guess_1
-        double x = 0.;  // lane j (< 16): walked input of segment j
-        if (lane == 1) x = a0;
-        double res = 0.;
-        for (int guard = 0; guard < 17; guard++) {
-          // ---- walk: a scalar integer chain (del is wave-uniform), no memory
-          // (branch-free: steps before `first` run on don't-care values and are overridden at j == first)
-          int myd = 0, d = del;
-#pragma unroll
-          for (int j = 1; j < 15; j++) {
-            d = (j == first) ? del : d;
-            const int m = d & 3, q = d - m;
-            const int dn = __builtin_amdgcn_readlane(dv, 4 * j + m);
-            d = dn + ((q << skl[j]) >> skr[j]);
-            if (lane == j + 1) myd = d;
-          }
-          if (lane > first && lane < 16) x = gBase + (double)myd * gU;
-          // ---- P2: verify every boundary
-          const double xs = __shfl(x, jD);
-          res = mfma_pass30(paddr, xs);
-          const double xn = __shfl(x, jD < 15 ? jD + 1 : 15);
-          const bool bad = (jD < 15) && (__double_as_longlong(res) != __double_as_longlong(xn));
-          const unsigned long long mask = __ballot(bad);
-          if (mask == 0ull || (dbg & 16)) break;
-          int f = 0;  // first failing segment (D-layout lane of chain j: 16*(j&3) + 4*(j>>2))
-          while (f < 15 && !((mask >> (16 * (f & 3) + 4 * (f >> 2))) & 1ull)) f++;
-          f = __builtin_amdgcn_readfirstlane(f);
-          const double xt = bcast(res, 16 * (f & 3) + 4 * (f >> 2));  // exact x_{f+1}
-          if (lane == f + 1) x = xt;
-          first = f + 1;
-          const double bq = bcast(gBase, f + 1), iq = bcast(gIU, f + 1);
-          del = __builtin_amdgcn_readfirstlane((int)((xt - bq) * iq));
-        }
-        if (lane == 60) {  // chain 15 lives in D lanes 60..63
-          predv[sc] = res;
-          pbuf[sc][t & (CH - 1)] = res;
-        }
+      static_assert(T == 1920 && NT >= 512 && SEGP == 122, "SPEC is laid out for the (1280,640) stage, phases on waves 0..7");
+      // waves 0..7: channel = wave & 1, candidate group = wave >> 1, so that the two channels' walkers (waves 0, 1)
+      // and each channel's four candidate waves sit on different SIMDs
+      const int sc = wave & 1, grp = wave < 8 ? (wave >> 1) : -1;
+      long long rounds_ = 0;
+      const double res = spec_exact_sum((uint32_t)(uintptr_t)&prods[sc][0], sJ[sc], &sX1[sc], grp, grp == 0, dbg, rounds_);
+      if (grp == 0 && lane == 60) {
+        predv[sc] = res;
+        pbuf[sc][t & (CH - 1)] = res;
       }
     } else
     if (wave == 0) {
@@ -384,20 +430,9 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
 // channels in one workgroup) the tap update -- VALU-throughput bound -- has twice the SIMDs, and
 // the serial phases of one channel no longer wait for the other's verification retries.
 //
-// Per sample (3 barriers):
-//   products   w[i]*hist[i] -> LDS, 16 segments of 120, stride 122 (bank-conflict-free MFMA reads)
-//   P1         waves 0..3: every segment summed from +0 (one 30-step MFMA pass, 16 chains); the
-//              prefix of these sums = guessed segment inputs g_j; wave m then sums every segment
-//              EXACTLY from g_j + (m-2) ulp (second pass)
-//   walk       wave 0: the tables "input offset -> output offset" of the 15 boundaries are composed
-//              by doubling (3 rounds) and evaluated for all boundaries at once (4 rounds), instead
-//              of a 15-step serial walk
-//   P2         wave 0: every segment re-summed exactly from its walked input; each output must equal
-//              the next walked input bit for bit. By induction from x_0 = +0 the last output then
-//              IS the strict left-to-right sum (nlms.h:110-111). A mismatch pins the first wrong
-//              boundary to the exact value just computed and re-evaluates the later ones.
-//   update     nlms.h:114-129, all threads
-// Everything before P2 is a guess and only affects speed; exactness rests on P2 alone.
+// Per sample (3 barriers): products w[i]*hist[i] -> LDS (16 segments of 120, stride 122: bank-conflict-free
+// MFMA operand reads) | spec_exact_sum (waves 0..3 sum candidates, wave 0 walks and verifies) | update
+// (nlms.h:114-129, all threads). Predictions are buffered in LDS and written out once per 256 samples.
 // ------------------------------------------------------------------------------------------
 #define L1_NT 512
 #define L1_R 4
@@ -419,11 +454,6 @@ __device__ __forceinline__ double rsq_emul2(double a, const float *tab, int bits
   return (double)__uint_as_float(tb);
 }
 
-__device__ __forceinline__ int ulp_shift(int v, int ea, int eb) {  // offset in ulps 2^ea -> ulps 2^eb (guess only)
-  int ks = (ea && eb) ? ea - eb : 0;
-  ks = ks > 31 ? 31 : (ks < -31 ? -31 : ks);
-  return ks >= 0 ? (int)((uint32_t)v << ks) : ((v + (1 << (-ks - 1))) >> (-ks));  // to nearest: the likelier of the two outcomes
-}
 
 __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs, const float *__restrict__ gtab, int bits) {
   constexpr int S = 1280, T = 1920, NT = L1_NT, R = L1_R, CH = L1_CH, MO = L1_RLO - 1, MX = L1_RLX - 1;
@@ -475,11 +505,6 @@ __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs
     for (int k = tid; k < L1_RLX - CH; k += NT) { const int tau = t0 - (L1_RLX - CH) + k; ringx[tau & MX] = tau >= 0 ? xx_in[tau] : 0.; }
   }
   const int lane = tid & 63, wave = tid >> 6;
-  const int jA = lane & 15, kA = lane >> 4;                      // A-operand lane: chain jA, term 4s+kA at step s
-  const int jD = 4 * ((lane >> 2) & 3) + (lane >> 4);             // chain held by this D-layout lane
-  const int dl = 16 * (lane & 3) + 4 * ((lane >> 2) & 3);         // D-layout lane of chain (lane & 15)
-  const int tj = lane >> 2, tm = lane & 3;                        // walk layout: boundary tj, input offset tm
-  const uint32_t paddr = (uint32_t)(uintptr_t)&prods[jA * SEGP + kA];
   long long rounds = 0;
 
   auto flush = [&](int tb, int te) {  // p and val[k+1] = x - p (CalcError, profile.cpp:141-148) for times [tb, te)
@@ -511,101 +536,11 @@ __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs
       if (valid[r]) prods[pa[r]] = w[r] * h[r];
     }
     __syncthreads();
-    // ---- P1: exact segment sums from the 16 candidate inputs g_j + (m-8) ulp. The four columns of the 4x4
-    // MFMA output share their A terms (B == 1) but keep their own C, so one wave sums every segment from four
-    // different inputs at once: wave w, column c -> candidate 4w + c.
-    double gBase = 0., gU = 0., gIU = 0.;  // lane l: boundary (l & 15)
-    if (wave < 4) {
-      // guess: every segment summed from +0 (exact for segment 0), prefix in any order
-      const double A = __shfl(mfma_pass30(paddr, 0.), dl);
-      double sh = row_prefix16(A);
-      sh -= A;
-      const double a0 = bcast(A, 0);
-      if (jA == 1) sh = a0;  // x_1 is known exactly
-      if (jA == 0) sh = 0.;
-      gU = ulp_pow2(sh, &gIU);
-      gBase = sh - 8. * gU;
-      const int m16 = 4 * wave + (lane & 3);
-      const double stv = __shfl(gBase, jD) + (double)m16 * __shfl(gU, jD);
-      const int nbD = jD < 15 ? jD + 1 : 15;
-      const double nB = __shfl(gBase, nbD), nIU = __shfl(gIU, nbD);
-      const double o = mfma_pass30(paddr, stv);
-      // table entry: offset on the next boundary's grid of this segment's output
-      sJ[0][jD][m16] = (jD < 15) ? (int)((o - nB) * nIU) : 0;
-      if (jD == 0 && m16 == 0) sX1 = o;  // segment 0 summed from +0: x_1, exact
-    }
-    __syncthreads();
-    // ---- walk + P2 (wave 0)
-    if (wave == 0) {
-      const int ex = (__double2hiint(gU) >> 20) & 0x7ff;  // lane l: exponent field of the ulp at boundary l & 15 (0: no grid)
-      const double bB = __shfl(gBase, tj), bU = __shfl(gU, tj);
-      // sJ[k][j][m]: offset at boundary j + 2^k if the offset at boundary j is m (0..15); sJ[0] comes from the
-      // P1 waves, lane (tj, tm) builds the entries m = tm + 4c of the others. One wave: its LDS operations
-      // complete in program order.
-      int Jc[4];
-#pragma unroll
-      for (int c = 0; c < 4; c++) Jc[c] = sJ[0][tj][tm + 4 * c];
-#pragma unroll
-      for (int k = 0; k < 3; k++) {
-        const int p = (tj + (1 << k)) < 15 ? tj + (1 << k) : 15, tg = (tj + (2 << k)) < 15 ? tj + (2 << k) : 15;
-        const int ea = __shfl(ex, p), eb = __shfl(ex, tg);
-        int f[4];
-#pragma unroll
-        for (int c = 0; c < 4; c++) f[c] = sJ[k][p][Jc[c] & 15];
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-          Jc[c] = f[c] + ulp_shift(Jc[c] - (Jc[c] & 15), ea, eb);
-          sJ[k + 1][tj][tm + 4 * c] = Jc[c];
-        }
-        __builtin_amdgcn_wave_barrier();
-      }
-      double x = 0.;  // lane group tj: walked input of segment tj (x_0 = +0 exactly)
-      if (tj == 1) x = sX1;
-      int sp = 1;                                         // boundaries <= sp are exact
-      int sd = sJ[0][0][0];                               // offset of x_sp on boundary sp's grid
-      double res = 0.;
-      for (int guard = 0; guard < 17; guard++) {
-        // ---- evaluate the boundaries after sp: binary decomposition of the distance
-        const int n = tj - sp;
-        int pk[5], ek[5];  // positions visited (they depend on the distance only) and their grid exponents
-        pk[4] = sp;
-#pragma unroll
-        for (int k = 3; k >= 0; k--) {
-          const bool take = n > 0 && ((n >> k) & 1);
-          const int pn = (pk[k + 1] + (1 << k)) < 15 ? pk[k + 1] + (1 << k) : 15;
-          pk[k] = take ? pn : pk[k + 1];
-        }
-#pragma unroll
-        for (int k = 0; k < 5; k++) ek[k] = __shfl(ex, pk[k]);
-        int dv = sd;
-#pragma unroll
-        for (int k = 3; k >= 0; k--) {
-          const int mm = dv & 15;
-          const int f = sJ[k][pk[k + 1]][mm];
-          if (pk[k] != pk[k + 1]) dv = f + ulp_shift(dv - mm, ek[k + 1], ek[k]);
-        }
-        if (n > 0) x = bB + (double)dv * bU;
-        // ---- P2: verify every boundary
-        const double xs = __shfl(x, 4 * jD);
-        const double xn = __shfl(x, 4 * (jD < 15 ? jD + 1 : 15));
-        res = mfma_pass30(paddr, xs);
-        const bool bad = (jD < 15) && (__double_as_longlong(res) != __double_as_longlong(xn));
-        const unsigned long long mask = __ballot(bad);
-        rounds++;
-        if (mask == 0ull || (dbg & 16)) break;
-        int f = 0;  // first failing segment (D-layout lane of chain j: 16*(j&3) + 4*(j>>2))
-        while (f < 15 && !((mask >> (16 * (f & 3) + 4 * (f >> 2))) & 1ull)) f++;
-        f = __builtin_amdgcn_readfirstlane(f);
-        const double xt = bcast(res, 16 * (f & 3) + 4 * (f >> 2));  // exact x_{f+1}
-        if (tj == f + 1) x = xt;
-        sp = f + 1;
-        const double bq = bcast(gBase, f + 1), iq = bcast(gIU, f + 1);
-        sd = __builtin_amdgcn_readfirstlane((int)((xt - bq) * iq));
-      }
-      if (lane == 60) {  // chain 15 lives in D lanes 60..63
-        predv = res;
-        pbuf[t & (CH - 1)] = res;
-      }
+    // ---- pred = 0.; for i: pred += w[i]*hist[i]  -- strict order (spec_exact_sum: waves 0..3 sum candidates, wave 0 verifies)
+    const double res = spec_exact_sum((uint32_t)(uintptr_t)&prods[0], sJ, &sX1, wave < 4 ? wave : -1, wave == 0, dbg, rounds);
+    if (wave == 0 && lane == 60) {
+      predv = res;
+      pbuf[t & (CH - 1)] = res;
     }
     __syncthreads();
     // ---- Update (nlms.h:114-129)
