@@ -7,6 +7,11 @@
 
 #define LMS_CHUNK 512     // samples staged into the LDS history ring at a time
 #define RSQ_LDS_MAX 8192  // rsqrt table entries kept in LDS (bits <= 12: Intel needs 10, AMD Zen 12)
+// Table entries as 16-bit words: the floats are in [0.5, 2) with the low mantissa byte clear (top byte 0x3F,
+// low byte 0), so bits 8..23 carry everything. sacopt_create checks that every entry fits.
+#define RSQ_PACKABLE(u) ((((u) >> 24) == 0x3Fu) && (((u) & 0xFFu) == 0u))
+#define RSQ_PACK(u) ((uint16_t)(((u) >> 8) & 0xFFFFu))
+#define RSQ_UNPACK(v) (0x3F000000u | ((uint32_t)(v) << 8))
 
 struct LmsJob {
   const double *x[2];  // stage inputs val[ch][k]      (n doubles each)

@@ -20,15 +20,17 @@
 
 // ------------------------------------------------------------------------------------------
 // x86 rsqrtss emulation (src/pred/nlms.h:34-57): f64 -> f32 (RNE), table on exponent parity x
-// top `bits` mantissa bits, exponent rescale, f32 -> f64.
+// top `bits` mantissa bits, exponent rescale, f32 -> f64. Table entries are floats in [0.5, 1) with at
+// most 15 significant mantissa bits (Intel and AMD: 12), kept as 16-bit words (jobs.h: RSQ_PACK) so that
+// the table costs 16 KB of LDS per workgroup instead of 32.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ double rsq_emul(double a, const float *tab, int bits) {
+__device__ __forceinline__ double rsq_emul(double a, const uint16_t *tab, int bits) {
   const float f = (float)a;
   const uint32_t u = __float_as_uint(f);
   const uint32_t e = (u >> 23) & 0xffu, mant = u & 0x7fffffu;
   const uint32_t par = e & 1u;
   const uint32_t idx = (par << bits) | (mant >> (23 - bits));
-  uint32_t tb = __float_as_uint(tab[idx]);
+  uint32_t tb = RSQ_UNPACK(tab[idx]);
   const int q = ((int)e - (par ? 127 : 128)) >> 1;  // e - ec is even: exact
   tb -= (uint32_t)(q << 23);
   if (e == 255u) tb = mant ? (u | 0x400000u) : 0u;  // NaN stays NaN, +inf -> +0
@@ -274,7 +276,7 @@ __device__ __forceinline__ double spec_exact_sum(uint32_t prods_addr, int (*sJ)[
 // go to LDS in the operand layout of the f64 MFMA, wave 0 sums them on the matrix pipe.
 // ------------------------------------------------------------------------------------------
 template <int S, int D, int NT, int R, int RL, bool SPEC>
-__global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, const float *__restrict__ gtab,
+__global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, const uint16_t *__restrict__ gtab,
                                             int bits) {
   constexpr int T = S + D, T4 = T / 4, M = RL - 1, CH = LMS_CHUNK;
   // SPEC: 16 segments of 120 products, padded to a stride of 122 doubles so that the 16 segment
@@ -293,7 +295,7 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
   // speculative exact summation (SPEC): boundary tables of spec_exact_sum, per channel
   __shared__ int sJ[SPEC ? 2 : 1][4][16][16];
   __shared__ double sX1[2];
-  __shared__ float tab[RSQ_LDS_MAX];
+  __shared__ uint16_t tab[RSQ_LDS_MAX];
 
   const LmsJob job = jobs[blockIdx.x];
   const int tid = threadIdx.x, t0 = job.t0, tend = job.t0 + job.n;
@@ -445,17 +447,17 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
 // rsq_emul with the integer part folded (argument is eg + 0.001 > 0 or NaN):
 //   index  = bits [23-bits, 23] of the float (top mantissa bits + exponent parity)
 //   rescale: table value * 2^-q, q = ((e+1)>>1) - 64
-__device__ __forceinline__ double rsq_emul2(double a, const float *tab, int bits) {
+__device__ __forceinline__ double rsq_emul2(double a, const uint16_t *tab, int bits) {
   const uint32_t u = __float_as_uint((float)a);
   const uint32_t idx = (u >> (23 - bits)) & ((2u << bits) - 1u);
   const uint32_t x = ((u + 0x800000u) >> 1) & 0x7f800000u;
-  uint32_t tb = __float_as_uint(tab[idx]) + (0x20000000u - x);
+  uint32_t tb = RSQ_UNPACK(tab[idx]) + (0x20000000u - x);
   if ((u & 0x7f800000u) == 0x7f800000u) tb = (u & 0x7fffffu) ? (u | 0x400000u) : 0u;  // NaN stays NaN, +inf -> +0
   return (double)__uint_as_float(tb);
 }
 
 
-__global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs, const float *__restrict__ gtab, int bits) {
+__global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs, const uint16_t *__restrict__ gtab, int bits) {
   constexpr int S = 1280, T = 1920, NT = L1_NT, R = L1_R, CH = L1_CH, MO = L1_RLO - 1, MX = L1_RLX - 1;
   constexpr int SEG = L1_SEG, SEGP = L1_SEGP;
   __shared__ double prods[16 * SEGP];
@@ -465,7 +467,7 @@ __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs
   __shared__ int sJ[4][16][16];
   __shared__ double sX1;
   __shared__ double predv;
-  __shared__ float tab[RSQ_LDS_MAX];
+  __shared__ uint16_t tab[RSQ_LDS_MAX];
 
   const LmsJob job = jobs[blockIdx.x >> 1];
   const int c = blockIdx.x & 1;
@@ -1211,7 +1213,7 @@ extern "C" int sacopt_lms_variant(int S, int D, int njobs, int bits) {
   if (S != 1280 || D != 640) return 0;
   return (!((bits >> 8) & (8 | 256)) && (njobs <= 100 || ((bits >> 8) & 512))) ? 1 : 0;
 }
-extern "C" int sacopt_launch_lms(int S, int D, const LmsJob *jobs, int njobs, const float *tab, int bits,
+extern "C" int sacopt_launch_lms(int S, int D, const LmsJob *jobs, int njobs, const uint16_t *tab, int bits,
                                  hipStream_t st) {
   if (njobs <= 0) return 0;
   if (S == 1280 && D == 640) {

@@ -21,7 +21,7 @@
 
 extern "C" {
 int sacopt_lms_state_doubles(int S, int D);
-int sacopt_launch_lms(int S, int D, const LmsJob *jobs, int njobs, const float *tab, int bits, hipStream_t st);
+int sacopt_launch_lms(int S, int D, const LmsJob *jobs, int njobs, const uint16_t *tab, int bits, hipStream_t st);
 int sacopt_lms_variant(int S, int D, int njobs, int bits);
 int sacopt_launch_lpc3(const LpcJob *jobs, int njobs, int max_n, hipStream_t st);
 int sacopt_launch_lpc2(const LpcJob *jobs, int njobs, int max_n, hipStream_t st);
@@ -43,7 +43,7 @@ struct sacopt_ctx {
   hipStream_t sAall = nullptr;             // lead stage of the full-frame pass when it has more workgroups than sA's reserved CUs
   hipStream_t sD = nullptr;                // final-pass pipeline: stages behind the second LMS stage (may be NULL)
   std::vector<hipEvent_t> pipe_ev;         // events of the last call's pipeline
-  float *d_tab = nullptr;
+  uint16_t *d_tab = nullptr;  // rsqrtss table, RSQ_PACK'ed
   int bits = 0;
   int *d_pow2 = nullptr;
   std::string err;
@@ -247,8 +247,15 @@ extern "C" int sacopt_create(int device, const float *rsqrt_tab, int rsqrt_bits,
     if (hipStreamCreateWithPriority(&c->sC, hipStreamDefault, hi) != hipSuccess) return fail("hipStreamCreateWithPriority failed");
     c->sD = nullptr;  // full-frame followers all on sB
   }
-  if (hipMalloc(&c->d_tab, sizeof(float) * (2 << bits)) != hipSuccess) return fail("hipMalloc(table) failed");
-  if (hipMemcpy(c->d_tab, tab.data(), sizeof(float) * (2 << bits), hipMemcpyHostToDevice) != hipSuccess) return fail("table upload failed");
+  std::vector<uint16_t> packed(2 << bits);
+  for (int i = 0; i < (2 << bits); i++) {
+    uint32_t u;
+    memcpy(&u, &tab[i], 4);
+    if (!RSQ_PACKABLE(u)) return fail("rsqrtss table entry outside [0.5,1) or with more than 16 significant bits: not an rsqrtss table");
+    packed[i] = RSQ_PACK(u);
+  }
+  if (hipMalloc(&c->d_tab, sizeof(uint16_t) * (2 << bits)) != hipSuccess) return fail("hipMalloc(table) failed");
+  if (hipMemcpy(c->d_tab, packed.data(), sizeof(uint16_t) * (2 << bits), hipMemcpyHostToDevice) != hipSuccess) return fail("table upload failed");
   int pw[32];
   for (int k = 0; k < 31; k++) pw[k] = (int)ceil(log((double)(1 << k)) / log(2));  // codec.cpp:329 with THIS host's libm
   pw[31] = 31;
