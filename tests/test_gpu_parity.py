@@ -318,3 +318,13 @@ def test_full_size_frames_properties(ctx, oracle):
     ref = oracle.predict(2, L, R, maps=True)
     for k in ("e0", "e1", "u0", "u1", "m0", "m1", "maxbpn"):
         assert np.array_equal(full[0][k], ref[k]), k
+
+
+def test_create_rejects_non_rsqrt_table():
+    # the table is kept as 16-bit words in LDS: entries must look like rsqrtss results ([0.5, 2), low byte clear)
+    bad = np.full(2048, 3.0, np.float32)
+    with pytest.raises(sacopt.SacoptError):
+        sacopt.Context(0, bad, 10)
+    noisy = np.full(2048, np.float32(0.7071067811865476), np.float32)   # 24 significant bits
+    with pytest.raises(sacopt.SacoptError):
+        sacopt.Context(0, noisy, 10)
