@@ -50,7 +50,9 @@ typedef struct {
 /* The LMS stages use the x86 `rsqrtss` approximation (src/pred/nlms.h:34-57), whose value is
  * CPU-specific. rsqrt_tab/rsqrt_bits give the table to emulate: 2^(bits+1) floats indexed by
  * (exponent-field parity << bits) | top `bits` mantissa bits (see sacopt_probe_rsqrt).
- * rsqrt_tab == NULL: probe the CPU this process runs on (what the reference would use here). */
+ * rsqrt_tab == NULL: probe the CPU this process runs on (what the reference would use here).
+ * Entries must be rsqrtss-like: in [0.5, 2) with at most 16 significant bits (Intel and AMD produce 12);
+ * the table is kept as 16-bit words on the device and sacopt_create fails for anything else. */
 int sacopt_create(int device, const float *rsqrt_tab, int rsqrt_bits, sacopt_ctx **out);
 void sacopt_destroy(sacopt_ctx *ctx);
 const char *sacopt_last_error(const sacopt_ctx *ctx); /* ctx may be NULL: error of a failed create */
