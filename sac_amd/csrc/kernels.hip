@@ -117,6 +117,37 @@ __device__ __forceinline__ double mfma_pass30(uint32_t addr, double acc) {
 }
 #undef MF
 
+// Same for 16 segments x 128 products (32 steps)
+#define MF(areg) "v_mfma_f64_4x4x4_4b_f64 %0, " areg ", %2, %0\n s_nop 3\n"
+__device__ __forceinline__ double mfma_pass32(uint32_t addr, double acc) {
+  double one = 1.0;
+  double a0, a1, a2, a3, a4, a5, a6, a7, b0, b1, b2, b3, b4, b5, b6, b7;
+  asm volatile(
+      "ds_read_b64 %3, %1\n ds_read_b64 %4, %1 offset:32\n ds_read_b64 %5, %1 offset:64\n ds_read_b64 %6, %1 offset:96\n"
+      "ds_read_b64 %7, %1 offset:128\n ds_read_b64 %8, %1 offset:160\n ds_read_b64 %9, %1 offset:192\n ds_read_b64 %10, %1 offset:224\n"
+      "ds_read_b64 %11, %1 offset:256\n ds_read_b64 %12, %1 offset:288\n ds_read_b64 %13, %1 offset:320\n ds_read_b64 %14, %1 offset:352\n"
+      "ds_read_b64 %15, %1 offset:384\n ds_read_b64 %16, %1 offset:416\n ds_read_b64 %17, %1 offset:448\n ds_read_b64 %18, %1 offset:480\n"
+      "s_waitcnt lgkmcnt(8)\n s_nop 1\n"
+      MF("%3") MF("%4") MF("%5") MF("%6") MF("%7") MF("%8") MF("%9") MF("%10")
+      "ds_read_b64 %3, %1 offset:512\n ds_read_b64 %4, %1 offset:544\n ds_read_b64 %5, %1 offset:576\n ds_read_b64 %6, %1 offset:608\n"
+      "ds_read_b64 %7, %1 offset:640\n ds_read_b64 %8, %1 offset:672\n ds_read_b64 %9, %1 offset:704\n ds_read_b64 %10, %1 offset:736\n"
+      "s_waitcnt lgkmcnt(8)\n s_nop 1\n"
+      MF("%11") MF("%12") MF("%13") MF("%14") MF("%15") MF("%16") MF("%17") MF("%18")
+      "ds_read_b64 %11, %1 offset:768\n ds_read_b64 %12, %1 offset:800\n ds_read_b64 %13, %1 offset:832\n ds_read_b64 %14, %1 offset:864\n"
+      "ds_read_b64 %15, %1 offset:896\n ds_read_b64 %16, %1 offset:928\n ds_read_b64 %17, %1 offset:960\n ds_read_b64 %18, %1 offset:992\n"
+      "s_waitcnt lgkmcnt(8)\n s_nop 1\n"
+      MF("%3") MF("%4") MF("%5") MF("%6") MF("%7") MF("%8") MF("%9") MF("%10")
+      "s_waitcnt lgkmcnt(0)\n s_nop 1\n"
+      MF("%11") MF("%12") MF("%13") MF("%14") MF("%15") MF("%16") MF("%17") MF("%18")
+      "s_nop 7\n"
+      : "+v"(acc), "+v"(addr), "+v"(one), "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(a4), "=&v"(a5), "=&v"(a6),
+        "=&v"(a7), "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3), "=&v"(b4), "=&v"(b5), "=&v"(b6), "=&v"(b7)
+      :
+      : "memory");
+  return acc;
+}
+#undef MF
+
 // Lane i of every 16-lane row receives the value of lane i-O of the same row (0. for i < O): DPP row_shr.
 template <int O>
 __device__ __forceinline__ double row_shr(double v) {
@@ -171,9 +202,13 @@ __device__ __forceinline__ int ulp_shift(int v, int ea, int eb) {  // offset in 
 //         later ones (each round fixes at least one boundary).
 // Everything before P2 only affects speed; exactness rests on P2 alone.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ double spec_exact_sum(uint32_t prods_addr, int (*sJ)[16][16], double *sX1, int group, bool walker,
-                                                 int dbg, long long &rounds) {
-  constexpr int SEGP = 122;
+// NSEG segments (chains NSEG..15 idle) of 4*STEPS products, segment stride SEGP doubles. sA != NULL: approximate
+// segment sums are supplied (the guess) instead of being computed by a pass from +0.
+template <int NSEG, int STEPS, int SEGP>
+__device__ __forceinline__ double spec_exact_sum(uint32_t prods_addr, int (*sJ)[16][16], double *sX1, const double *sA, int group,
+                                                 bool walker, int dbg, long long &rounds) {
+  constexpr int NB = NSEG - 1;  // last boundary = input of the last segment
+  auto pass = [](uint32_t ad, double c0) { return STEPS == 30 ? mfma_pass30(ad, c0) : mfma_pass32(ad, c0); };
   const int lane = threadIdx.x & 63;
   const int jA = lane & 15, kA = lane >> 4;                      // A-operand lane: chain jA, term 4s+kA at step s
   const int jD = 4 * ((lane >> 2) & 3) + (lane >> 4);             // chain held by this D-layout lane
@@ -182,7 +217,7 @@ __device__ __forceinline__ double spec_exact_sum(uint32_t prods_addr, int (*sJ)[
   const uint32_t paddr = prods_addr + (uint32_t)(jA * SEGP + kA) * 8u;
   double gBase = 0., gU = 0., gIU = 0.;  // lane l: boundary (l & 15)
   if (group >= 0) {
-    const double A = __shfl(mfma_pass30(paddr, 0.), dl);
+    const double A = sA ? (jA < NSEG ? sA[jA] : 0.) : __shfl(pass(paddr, 0.), dl);
     double sh = row_prefix16(A);  // any order: only a guess
     sh -= A;
     const double a0 = bcast(A, 0);
@@ -192,10 +227,10 @@ __device__ __forceinline__ double spec_exact_sum(uint32_t prods_addr, int (*sJ)[
     gBase = sh - 8. * gU;
     const int m16 = 4 * group + (lane & 3);
     const double stv = __shfl(gBase, jD) + (double)m16 * __shfl(gU, jD);
-    const int nbD = jD < 15 ? jD + 1 : 15;
+    const int nbD = jD < NB ? jD + 1 : NB;
     const double nB = __shfl(gBase, nbD), nIU = __shfl(gIU, nbD);
-    const double o = mfma_pass30(paddr, stv);
-    sJ[0][jD][m16] = (jD < 15) ? (int)((o - nB) * nIU) : 0;
+    const double o = pass(paddr, stv);
+    sJ[0][jD][m16] = (jD < NB) ? (int)((o - nB) * nIU) : 0;
     if (jD == 0 && m16 == 0) *sX1 = o;  // segment 0 summed from +0: x_1, exact
   }
   __syncthreads();
@@ -209,7 +244,7 @@ __device__ __forceinline__ double spec_exact_sum(uint32_t prods_addr, int (*sJ)[
     for (int c = 0; c < 4; c++) Jc[c] = sJ[0][tj][tm + 4 * c];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-      const int p = (tj + (1 << k)) < 15 ? tj + (1 << k) : 15, tg = (tj + (2 << k)) < 15 ? tj + (2 << k) : 15;
+      const int p = (tj + (1 << k)) < NB ? tj + (1 << k) : NB, tg = (tj + (2 << k)) < NB ? tj + (2 << k) : NB;
       const int ea = __shfl(ex, p), eb = __shfl(ex, tg);
       int f[4];
 #pragma unroll
@@ -233,7 +268,7 @@ __device__ __forceinline__ double spec_exact_sum(uint32_t prods_addr, int (*sJ)[
 #pragma unroll
       for (int k = 3; k >= 0; k--) {
         const bool take = n > 0 && ((n >> k) & 1);
-        const int pn = (pk[k + 1] + (1 << k)) < 15 ? pk[k + 1] + (1 << k) : 15;
+        const int pn = (pk[k + 1] + (1 << k)) < NB ? pk[k + 1] + (1 << k) : NB;
         pk[k] = take ? pn : pk[k + 1];
       }
 #pragma unroll
@@ -248,14 +283,14 @@ __device__ __forceinline__ double spec_exact_sum(uint32_t prods_addr, int (*sJ)[
       if (n > 0) x = bB + (double)dv * bU;
       // ---- P2: verify every boundary
       const double xs = __shfl(x, 4 * jD);
-      const double xn = __shfl(x, 4 * (jD < 15 ? jD + 1 : 15));
-      res = mfma_pass30(paddr, xs);
-      const bool bad = (jD < 15) && (__double_as_longlong(res) != __double_as_longlong(xn));
+      const double xn = __shfl(x, 4 * (jD < NB ? jD + 1 : NB));
+      res = pass(paddr, xs);
+      const bool bad = (jD < NB) && (__double_as_longlong(res) != __double_as_longlong(xn));
       const unsigned long long mask = __ballot(bad);
       rounds++;
       if (mask == 0ull || (dbg & 16)) break;
       int f = 0;  // first failing segment (D-layout lane of chain j: 16*(j&3) + 4*(j>>2))
-      while (f < 15 && !((mask >> (16 * (f & 3) + 4 * (f >> 2))) & 1ull)) f++;
+      while (f < NB && !((mask >> (16 * (f & 3) + 4 * (f >> 2))) & 1ull)) f++;
       f = __builtin_amdgcn_readfirstlane(f);
       const double xt = bcast(res, 16 * (f & 3) + 4 * (f >> 2));  // exact x_{f+1}
       if (tj == f + 1) x = xt;
@@ -264,7 +299,7 @@ __device__ __forceinline__ double spec_exact_sum(uint32_t prods_addr, int (*sJ)[
       sd = __builtin_amdgcn_readfirstlane((int)((xt - bq) * iq));
     }
   }
-  return res;  // chain 15 lives in D lanes 60..63
+  return res;  // chain NB lives in D lanes 16*(NB&3) + 4*(NB>>2) + {0..3}
 }
 
 // ------------------------------------------------------------------------------------------
@@ -377,7 +412,7 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
       // and each channel's four candidate waves sit on different SIMDs
       const int sc = wave & 1, grp = wave < 8 ? (wave >> 1) : -1;
       long long rounds_ = 0;
-      const double res = spec_exact_sum((uint32_t)(uintptr_t)&prods[sc][0], sJ[sc], &sX1[sc], grp, grp == 0, dbg, rounds_);
+      const double res = spec_exact_sum<16, 30, 122>((uint32_t)(uintptr_t)&prods[sc][0], sJ[sc], &sX1[sc], nullptr, grp, grp == 0, dbg, rounds_);
       if (grp == 0 && lane == 60) {
         predv[sc] = res;
         pbuf[sc][t & (CH - 1)] = res;
@@ -441,8 +476,8 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
 #define L1_CH 256
 #define L1_RLO 2048
 #define L1_RLX 1024
-#define L1_SEG 120
-#define L1_SEGP 122
+#define L1_SEG 128   // products per segment (32 MFMA steps)
+#define L1_SEGP 130  // segment stride in LDS: the 16 chain lanes of a ds_read_b64 half on 16 different 4-bank groups
 
 // rsq_emul with the integer part folded (argument is eg + 0.001 > 0 or NaN):
 //   index  = bits [23-bits, 23] of the float (top mantissa bits + exponent parity)
@@ -459,8 +494,9 @@ __device__ __forceinline__ double rsq_emul2(double a, const uint16_t *tab, int b
 
 __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs, const uint16_t *__restrict__ gtab, int bits) {
   constexpr int S = 1280, T = 1920, NT = L1_NT, R = L1_R, CH = L1_CH, MO = L1_RLO - 1, MX = L1_RLX - 1;
-  constexpr int SEG = L1_SEG, SEGP = L1_SEGP;
+  constexpr int SEG = L1_SEG, SEGP = L1_SEGP, NSEG = T / SEG;  // 15 segments of 128 products
   __shared__ double prods[16 * SEGP];
+  __shared__ double sA[16];  // approximate segment sums (the guess of spec_exact_sum)
   __shared__ double ringo[L1_RLO];  // own channel's stage inputs   (taps 0..1279: lags 1..1280)
   __shared__ double ringx[L1_RLX];  // other channel's stage inputs (taps 1280..1919)
   __shared__ double pbuf[CH];
@@ -482,6 +518,7 @@ __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs
   for (int i = tid; i < (2 << bits); i += NT) tab[i] = gtab[i];
   for (int i = tid; i < L1_RLO; i += NT) ringo[i] = 0.;
   for (int i = tid; i < L1_RLX; i += NT) ringx[i] = 0.;
+  for (int i = tid; i < 16 * SEGP; i += NT) prods[i] = 0.;  // chain 15 of the MFMA passes is idle: keep its operands finite
   __syncthreads();
 
   double w[R], eg[R], mu[R];
@@ -491,13 +528,18 @@ __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs
   // carried state: same layout as k_lms<1280,640,...> (w at [tap], eg at [4096 + tap], tap = channel*1920 + i),
   // so the two kernels may alternate between the chunks of one chain
   double *st = job.state ? job.state + c * T : nullptr;
+  // Half-wave `seg` (32 threads) owns the 128 taps of segment `seg`, lane l the taps l, 32+l, 64+l, 96+l of it:
+  // consecutive lanes read consecutive history values, and a segment's approximate sum is a half-wave reduction.
+  const int seg = tid >> 5, hl = tid & 31;
+  int tap[R];
 #pragma unroll
   for (int r = 0; r < R; r++) {
-    const int i = r * NT + tid;
-    valid[r] = i < T;
+    const int i = SEG * seg + 32 * r + hl;
+    tap[r] = i;
+    valid[r] = seg < NSEG;
     if (i < S) { hb[r] = ringo; hmask[r] = MO; hoff[r] = (-(1 + i)) & MO; mu[r] = job.mu1; }
     else { hb[r] = ringx; hmask[r] = MX; hoff[r] = (-(lagx + (i - S))) & MX; mu[r] = job.mu2; }
-    pa[r] = (i / SEG) * SEGP + (i % SEG);
+    pa[r] = seg * SEGP + 32 * r + hl;
     if (!valid[r]) { hb[r] = ringo; hmask[r] = MO; hoff[r] = 0; pa[r] = 0; }
     w[r] = 0.; eg[r] = 0.;
     if (t0 > 0 && st && valid[r]) { w[r] = st[i]; eg[r] = st[4096 + i]; }
@@ -531,16 +573,27 @@ __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs
       __syncthreads();
     }
     // ---- products w[i]*hist[i] (nlms.h:111)
-    double h[R];
+    double h[R], part = 0.;
 #pragma unroll
     for (int r = 0; r < R; r++) {
       h[r] = hb[r][(t + hoff[r]) & hmask[r]];
-      if (valid[r]) prods[pa[r]] = w[r] * h[r];
+      const double pr = w[r] * h[r];
+      if (valid[r]) prods[pa[r]] = pr;
+      part += pr;
     }
+    // approximate segment sum (tree order: a guess only): 16-lane rows by DPP, then row 0 -> 1 and row 2 -> 3
+    part = row_prefix16(part);
+    {
+      int lo = __double2loint(part), hi = __double2hiint(part);
+      lo = __builtin_amdgcn_update_dpp(0, lo, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1 and 3
+      hi = __builtin_amdgcn_update_dpp(0, hi, 0x142, 0xA, 0xF, false);
+      part += __hiloint2double(hi, lo);
+    }
+    if (hl == 31 && valid[0]) sA[seg] = part;
     __syncthreads();
     // ---- pred = 0.; for i: pred += w[i]*hist[i]  -- strict order (spec_exact_sum: waves 0..3 sum candidates, wave 0 verifies)
-    const double res = spec_exact_sum((uint32_t)(uintptr_t)&prods[0], sJ, &sX1, wave < 4 ? wave : -1, wave == 0, dbg, rounds);
-    if (wave == 0 && lane == 60) {
+    const double res = spec_exact_sum<NSEG, SEG / 4, SEGP>((uint32_t)(uintptr_t)&prods[0], sJ, &sX1, sA, wave < 4 ? wave : -1, wave == 0, dbg, rounds);
+    if (wave == 0 && lane == 16 * ((NSEG - 1) & 3) + 4 * ((NSEG - 1) >> 2)) {
       predv = res;
       pbuf[t & (CH - 1)] = res;
     }
@@ -564,7 +617,7 @@ __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs
   if (st) {
 #pragma unroll
     for (int r = 0; r < R; r++)
-      if (valid[r]) { st[r * NT + tid] = w[r]; st[4096 + r * NT + tid] = eg[r]; }
+      if (valid[r]) { st[tap[r]] = w[r]; st[4096 + tap[r]] = eg[r]; }
   }
 }
 
