@@ -83,41 +83,10 @@ __device__ __forceinline__ double mfma_chain_lds(uint32_t addr) {
 #undef MF
 
 
-// One MFMA adder pass over 16 segments x 120 products: chain j (segment j) starts from the value
+// One MFMA adder pass over 16 segments x 128 products: chain j (segment j) starts from the value
 // its D-layout lanes hold in `acc`, lane (k = lane>>4, j = lane&15) feeds term 4s+k of segment j
-// at step s (30 steps, 32 bytes apart from `addr`). Returns D: lanes 16*i+4*blk+{0..3} hold chain
+// at step s (32 steps, 32 bytes apart from `addr`). Returns D: lanes 16*i+4*blk+{0..3} hold chain
 // 4*blk+i. Straight-line, operands of the next group of 8 always in flight.
-#define MF(areg) "v_mfma_f64_4x4x4_4b_f64 %0, " areg ", %2, %0\n s_nop 3\n"
-__device__ __forceinline__ double mfma_pass30(uint32_t addr, double acc) {
-  double one = 1.0;
-  double a0, a1, a2, a3, a4, a5, a6, a7, b0, b1, b2, b3, b4, b5, b6, b7;
-  asm volatile(
-      "ds_read_b64 %3, %1\n ds_read_b64 %4, %1 offset:32\n ds_read_b64 %5, %1 offset:64\n ds_read_b64 %6, %1 offset:96\n"
-      "ds_read_b64 %7, %1 offset:128\n ds_read_b64 %8, %1 offset:160\n ds_read_b64 %9, %1 offset:192\n ds_read_b64 %10, %1 offset:224\n"
-      "ds_read_b64 %11, %1 offset:256\n ds_read_b64 %12, %1 offset:288\n ds_read_b64 %13, %1 offset:320\n ds_read_b64 %14, %1 offset:352\n"
-      "ds_read_b64 %15, %1 offset:384\n ds_read_b64 %16, %1 offset:416\n ds_read_b64 %17, %1 offset:448\n ds_read_b64 %18, %1 offset:480\n"
-      "s_waitcnt lgkmcnt(8)\n s_nop 1\n"
-      MF("%3") MF("%4") MF("%5") MF("%6") MF("%7") MF("%8") MF("%9") MF("%10")
-      "ds_read_b64 %3, %1 offset:512\n ds_read_b64 %4, %1 offset:544\n ds_read_b64 %5, %1 offset:576\n ds_read_b64 %6, %1 offset:608\n"
-      "ds_read_b64 %7, %1 offset:640\n ds_read_b64 %8, %1 offset:672\n ds_read_b64 %9, %1 offset:704\n ds_read_b64 %10, %1 offset:736\n"
-      "s_waitcnt lgkmcnt(8)\n s_nop 1\n"
-      MF("%11") MF("%12") MF("%13") MF("%14") MF("%15") MF("%16") MF("%17") MF("%18")
-      "ds_read_b64 %11, %1 offset:768\n ds_read_b64 %12, %1 offset:800\n ds_read_b64 %13, %1 offset:832\n ds_read_b64 %14, %1 offset:864\n"
-      "ds_read_b64 %15, %1 offset:896\n ds_read_b64 %16, %1 offset:928\n"
-      "s_waitcnt lgkmcnt(6)\n s_nop 1\n"
-      MF("%3") MF("%4") MF("%5") MF("%6") MF("%7") MF("%8") MF("%9") MF("%10")
-      "s_waitcnt lgkmcnt(0)\n s_nop 1\n"
-      MF("%11") MF("%12") MF("%13") MF("%14") MF("%15") MF("%16")
-      "s_nop 7\n"
-      : "+v"(acc), "+v"(addr), "+v"(one), "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(a4), "=&v"(a5), "=&v"(a6),
-        "=&v"(a7), "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3), "=&v"(b4), "=&v"(b5), "=&v"(b6), "=&v"(b7)
-      :
-      : "memory");
-  return acc;
-}
-#undef MF
-
-// Same for 16 segments x 128 products (32 steps)
 #define MF(areg) "v_mfma_f64_4x4x4_4b_f64 %0, " areg ", %2, %0\n s_nop 3\n"
 __device__ __forceinline__ double mfma_pass32(uint32_t addr, double acc) {
   double one = 1.0;
@@ -156,6 +125,8 @@ __device__ __forceinline__ double row_shr(double v) {
   hi = __builtin_amdgcn_update_dpp(0, hi, 0x110 + O, 0xf, 0xf, false);
   return __hiloint2double(hi, lo);
 }
+template <int O>
+__device__ __forceinline__ int row_shr_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x110 + O, 0xf, 0xf, false); }
 // Inclusive prefix sum over each 16-lane row (tree order: only ever used as a guess)
 __device__ __forceinline__ double row_prefix16(double v) {
   v += row_shr<1>(v);
@@ -180,48 +151,44 @@ __device__ __forceinline__ int ulp_shift(int v, int ea, int eb) {  // offset in 
 }
 
 // ------------------------------------------------------------------------------------------
-// Speculative exact summation of one 1920-term chain (16 segments x 120 products in LDS, segment
-// stride 122 doubles starting at LDS byte address prods_addr). Called by every wave of the workgroup
-// (it contains a workgroup barrier); `group` in 0..3 marks the four waves that sum candidates for this
-// chain, -1 the bystanders; `walker` is the one candidate wave (group 0) that follows the chain and
-// verifies it. Returns, in lane 60 of the walker, the strict left-to-right FP64 sum (nlms.h:110-111).
-//   P1    each candidate wave: every segment summed from +0 (30-step MFMA pass, 16 chains) -- the prefix
-//         of these sums guesses the segment inputs g_j -- then every segment summed EXACTLY from 16
-//         candidate inputs g_j + (m-8) ulp: the four columns of the 4x4 MFMA output share their A terms
-//         (B == 1) but keep their own C, so wave w, column c carries candidate 4w + c. Each output is
-//         stored as its offset on the next boundary's candidate grid: sJ[0][j][m].
-//   walk  sJ[k][j][m] (offset at boundary j + 2^k given offset m at j) by doubling, 3 rounds; then every
-//         boundary's offset from the exact x_1 by binary decomposition of its distance, 4 lookups.
-//         Offsets outside 0..15 are extended periodically (shift by 16q ulps, converted between binade
-//         grids): a guess, but a good one -- shifts by high powers of two survive the coarser binades a
-//         segment's partial sums pass through (4 candidates / shifts by 4q failed on 30-45 % of the
-//         samples, 16 fail on 5-12 %).
+// Speculative exact summation of one chain of NSEG segments x 4*STEPS products in LDS (segment stride SEGP
+// doubles starting at LDS byte address prods_addr; chains NSEG..15 of the MFMA passes idle). Called by every
+// wave of the workgroup (it contains a workgroup barrier); `group` in 0..3 marks the four waves that sum
+// candidates for this chain, -1 the bystanders; `walker` is the one candidate wave (group 0) that follows the
+// chain and verifies it. sA[j]: approximate sum of segment j (any order -- the caller's tree reduction).
+// Returns, in the D lanes of chain NSEG-1 of the walker, the strict left-to-right FP64 sum (nlms.h:110-111).
+//   P1    the prefix of sA guesses the segment inputs g_j (boundary j = input of segment j). Each candidate
+//         wave sums every segment EXACTLY from 16 candidate inputs g_j + (m-8) ulp: the four columns of the
+//         4x4 MFMA output share their A terms (B == 1) but keep their own C, so wave w, column c carries
+//         candidate 4w + c. Each output is stored as its offset on the next boundary's candidate grid:
+//         sJ[j][m] = offset at boundary j+1 given offset m at boundary j.
+//   walk  d_{l+1} = step_l(d_l) from the exact x_1, step_l(d) = sJ[l][d & 15] + (d - (d & 15)) converted to the
+//         next boundary's binade: offsets outside 0..15 are extended periodically (a shift by 16q ulps) -- a
+//         guess, but a good one: shifts by high powers of two survive the coarser binades a segment's partial
+//         sums pass through (4 candidates / shifts by 4q failed on 30-45 % of the samples, 16 fail on 5-9 %).
+//         The recursion is solved for all boundaries at once by a fixed-point iteration on DPP prefix sums.
 //   P2    every segment re-summed exactly from its walked input; each output must EQUAL the next walked
 //         input bit for bit. By induction from x_0 = +0 the last output then IS the sequential sum. A
-//         mismatch pins the first wrong boundary to the exact value just computed and re-evaluates the
-//         later ones (each round fixes at least one boundary).
+//         mismatch pins the first wrong boundary to the exact value just computed and re-walks the later
+//         ones (each round fixes at least one boundary).
 // Everything before P2 only affects speed; exactness rests on P2 alone.
 // ------------------------------------------------------------------------------------------
-// NSEG segments (chains NSEG..15 idle) of 4*STEPS products, segment stride SEGP doubles. sA != NULL: approximate
-// segment sums are supplied (the guess) instead of being computed by a pass from +0.
 template <int NSEG, int STEPS, int SEGP>
-__device__ __forceinline__ double spec_exact_sum(uint32_t prods_addr, int (*sJ)[16][16], double *sX1, const double *sA, int group,
+__device__ __forceinline__ double spec_exact_sum(uint32_t prods_addr, int (*sJ)[16], double *sX1, const double *sA, int group,
                                                  bool walker, int dbg, long long &rounds) {
   constexpr int NB = NSEG - 1;  // last boundary = input of the last segment
-  auto pass = [](uint32_t ad, double c0) { return STEPS == 30 ? mfma_pass30(ad, c0) : mfma_pass32(ad, c0); };
+  static_assert(STEPS == 32, "one pass = 32 MFMA steps");
+  auto pass = [](uint32_t ad, double c0) { return mfma_pass32(ad, c0); };
   const int lane = threadIdx.x & 63;
   const int jA = lane & 15, kA = lane >> 4;                      // A-operand lane: chain jA, term 4s+kA at step s
   const int jD = 4 * ((lane >> 2) & 3) + (lane >> 4);             // chain held by this D-layout lane
-  const int dl = 16 * (lane & 3) + 4 * ((lane >> 2) & 3);         // D-layout lane of chain (lane & 15)
-  const int tj = lane >> 2, tm = lane & 3;                        // walk layout: boundary tj, table entries tm + 4c
+  int walk_its = 0;
   const uint32_t paddr = prods_addr + (uint32_t)(jA * SEGP + kA) * 8u;
   double gBase = 0., gU = 0., gIU = 0.;  // lane l: boundary (l & 15)
   if (group >= 0) {
-    const double A = sA ? (jA < NSEG ? sA[jA] : 0.) : __shfl(pass(paddr, 0.), dl);
+    const double A = jA < NSEG ? sA[jA] : 0.;
     double sh = row_prefix16(A);  // any order: only a guess
     sh -= A;
-    const double a0 = bcast(A, 0);
-    if (jA == 1) sh = a0;  // x_1 is known exactly
     if (jA == 0) sh = 0.;
     gU = ulp_pow2(sh, &gIU);
     gBase = sh - 8. * gU;
@@ -230,60 +197,56 @@ __device__ __forceinline__ double spec_exact_sum(uint32_t prods_addr, int (*sJ)[
     const int nbD = jD < NB ? jD + 1 : NB;
     const double nB = __shfl(gBase, nbD), nIU = __shfl(gIU, nbD);
     const double o = pass(paddr, stv);
-    sJ[0][jD][m16] = (jD < NB) ? (int)((o - nB) * nIU) : 0;
+    sJ[jD][m16] = (jD < NB) ? (int)((o - nB) * nIU) : 0;
     if (jD == 0 && m16 == 0) *sX1 = o;  // segment 0 summed from +0: x_1, exact
   }
   __syncthreads();
   double res = 0.;
   if (walker) {
-    const int ex = (__double2hiint(gU) >> 20) & 0x7ff;  // lane l: exponent field of the ulp at boundary l & 15 (0: no grid)
-    const double bB = __shfl(gBase, tj), bU = __shfl(gU, tj);
-    // one wave: its LDS operations complete in program order
-    int Jc[4];
-#pragma unroll
-    for (int c = 0; c < 4; c++) Jc[c] = sJ[0][tj][tm + 4 * c];
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      const int p = (tj + (1 << k)) < NB ? tj + (1 << k) : NB, tg = (tj + (2 << k)) < NB ? tj + (2 << k) : NB;
-      const int ea = __shfl(ex, p), eb = __shfl(ex, tg);
-      int f[4];
-#pragma unroll
-      for (int c = 0; c < 4; c++) f[c] = sJ[k][p][Jc[c] & 15];
-#pragma unroll
-      for (int c = 0; c < 4; c++) {
-        Jc[c] = f[c] + ulp_shift(Jc[c] - (Jc[c] & 15), ea, eb);
-        sJ[k + 1][tj][tm + 4 * c] = Jc[c];
-      }
-      __builtin_amdgcn_wave_barrier();
-    }
-    double x = 0.;  // lane group tj: walked input of segment tj (x_0 = +0 exactly)
-    if (tj == 1) x = *sX1;
-    int sp = 1;              // boundaries <= sp are exact
-    int sd = sJ[0][0][0];    // offset of x_sp on boundary sp's grid
+    // lane l (every 16-lane row alike): boundary jA = l & 15; d = offset of x_jA on its candidate grid
+    const int ex = (__double2hiint(gU) >> 20) & 0x7ff;                         // exponent field of the ulp at boundary jA (0: no grid)
+    const int exn = __builtin_amdgcn_update_dpp(0, ex, 0x101, 0xf, 0xf, false);  // ... at boundary jA + 1 (row_shl:1)
+    // offsets of different boundaries count ulps of different binades: sh = log2(own ulp / finest ulp of the row), so
+    // that y = d << sh is one common unit in which a segment adds a constant to first order (a table is a shift by a
+    // constant in that unit unless partial sums leave the binades of its two ends)
+    int emin = (ex && jA >= 1 && jA <= NB) ? ex : 4095;
+    emin = min(emin, __builtin_amdgcn_update_dpp(emin, emin, 0x121, 0xf, 0xf, false));  // row_ror:1,2,4,8: all-reduce
+    emin = min(emin, __builtin_amdgcn_update_dpp(emin, emin, 0x122, 0xf, 0xf, false));
+    emin = min(emin, __builtin_amdgcn_update_dpp(emin, emin, 0x124, 0xf, 0xf, false));
+    emin = min(emin, __builtin_amdgcn_update_dpp(emin, emin, 0x128, 0xf, 0xf, false));
+    const int sh = ex ? min(ex - emin, 16) : 0;
+    const int shn = __builtin_amdgcn_update_dpp(0, sh, 0x101, 0xf, 0xf, false);
+    const int rnd = sh ? 1 << (sh - 1) : 0;
+    double x = 0.;  // x_0 = +0 exactly
+    if (jA == 1) x = *sX1;
+    int d = 8;
+    int sp = 1;            // boundaries <= sp are exact
+    int sd = sJ[0][0];     // offset of x_sp on boundary sp's grid
     for (int guard = 0; guard < 17; guard++) {
-      // ---- offsets of the boundaries after sp: binary decomposition of the distance
-      const int n = tj - sp;
-      int pk[5], ek[5];  // positions visited (they depend on the distance only) and their grid exponents
-      pk[4] = sp;
-#pragma unroll
-      for (int k = 3; k >= 0; k--) {
-        const bool take = n > 0 && ((n >> k) & 1);
-        const int pn = (pk[k + 1] + (1 << k)) < NB ? pk[k + 1] + (1 << k) : NB;
-        pk[k] = take ? pn : pk[k + 1];
+      // ---- walk: d_{l+1} = step_l(d_l) for l >= sp, solved for all boundaries at once: with inc_l = y(step_l(d_l)) -
+      // y(d_l) evaluated at the current estimates, y_l <- y_sp + sum_{sp <= i < l} inc_i (DPP prefix). A fixed point
+      // is the sequential walk (y is exact both ways there); every iteration makes at least one more boundary final.
+      if (jA == sp) d = sd;
+      const int ysp = sd << __builtin_amdgcn_readlane(sh, sp);
+      for (int it = 0; it < 16; it++) {
+        const int mm = d & 15;
+        int inc = ((sJ[jA][mm] + ulp_shift(d - mm, ex, exn)) << shn) - (d << sh);
+        if (jA < sp || jA >= NB) inc = 0;
+        inc += row_shr_i<1>(inc);
+        inc += row_shr_i<2>(inc);
+        inc += row_shr_i<4>(inc);
+        inc += row_shr_i<8>(inc);
+        const int before = row_shr_i<1>(inc);  // sum over i < jA
+        const int nd = (jA > sp) ? (ysp + before + rnd) >> sh : d;
+        const bool ch = nd != d;
+        d = nd;
+        walk_its++;
+        if (__ballot(ch) == 0ull) break;
       }
-#pragma unroll
-      for (int k = 0; k < 5; k++) ek[k] = __shfl(ex, pk[k]);
-      int dv = sd;
-#pragma unroll
-      for (int k = 3; k >= 0; k--) {
-        const int mm = dv & 15;
-        const int f = sJ[k][pk[k + 1]][mm];
-        if (pk[k] != pk[k + 1]) dv = f + ulp_shift(dv - mm, ek[k + 1], ek[k]);
-      }
-      if (n > 0) x = bB + (double)dv * bU;
+      if (jA > sp) x = gBase + (double)d * gU;
       // ---- P2: verify every boundary
-      const double xs = __shfl(x, 4 * jD);
-      const double xn = __shfl(x, 4 * (jD < NB ? jD + 1 : NB));
+      const double xs = __shfl(x, jD);
+      const double xn = __shfl(x, jD < NB ? jD + 1 : NB);
       res = pass(paddr, xs);
       const bool bad = (jD < NB) && (__double_as_longlong(res) != __double_as_longlong(xn));
       const unsigned long long mask = __ballot(bad);
@@ -293,11 +256,12 @@ __device__ __forceinline__ double spec_exact_sum(uint32_t prods_addr, int (*sJ)[
       while (f < NB && !((mask >> (16 * (f & 3) + 4 * (f >> 2))) & 1ull)) f++;
       f = __builtin_amdgcn_readfirstlane(f);
       const double xt = bcast(res, 16 * (f & 3) + 4 * (f >> 2));  // exact x_{f+1}
-      if (tj == f + 1) x = xt;
+      if (jA == f + 1) x = xt;
       sp = f + 1;
       const double bq = bcast(gBase, f + 1), iq = bcast(gIU, f + 1);
       sd = __builtin_amdgcn_readfirstlane((int)((xt - bq) * iq));
     }
+    if (dbg & 1024) rounds += (long long)walk_its << 32;
   }
   return res;  // chain NB lives in D lanes 16*(NB&3) + 4*(NB>>2) + {0..3}
 }
@@ -310,13 +274,15 @@ __device__ __forceinline__ double spec_exact_sum(uint32_t prods_addr, int (*sJ)[
 // is a ring of stage inputs in LDS (shifts of nlms.h:109,130 become index arithmetic), products
 // go to LDS in the operand layout of the f64 MFMA, wave 0 sums them on the matrix pipe.
 // ------------------------------------------------------------------------------------------
+#define L1_SEG 128   // products per segment (32 MFMA steps)
+#define L1_SEGP 130  // segment stride in LDS: the 16 chain lanes of a ds_read_b64 half on 16 different 4-bank groups
 template <int S, int D, int NT, int R, int RL, bool SPEC>
 __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, const uint16_t *__restrict__ gtab,
                                             int bits) {
   constexpr int T = S + D, T4 = T / 4, M = RL - 1, CH = LMS_CHUNK;
-  // SPEC: 16 segments of 120 products, padded to a stride of 122 doubles so that the 16 segment
-  // lanes of a ds_read_b64 half fall on 16 different 4-bank groups (stride 120 -> 4-way conflict)
-  constexpr int SEG = 120, SEGP = 122, TP = SPEC ? 16 * SEGP : T + 4;  // T + 4: the two channels' MFMA operands on different banks
+  // SPEC: 15 segments of 128 products, padded to a stride of 130 doubles so that the 16 segment
+  // lanes of a ds_read_b64 half fall on 16 different 4-bank groups
+  constexpr int SEG = L1_SEG, SEGP = L1_SEGP, NSEG = 15, TP = SPEC ? 16 * SEGP : T + 4;  // T + 4: the two channels' MFMA operands on different banks
   static_assert(T % 4 == 0, "tap count must be a multiple of 4");
   static_assert(RL >= CH + (S > D ? S : D) + 1, "ring too short");
   static_assert(NT * R >= 2 * T, "not enough tap slots");
@@ -328,8 +294,9 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
   // sample would put an HBM write round trip in front of every barrier)
   __shared__ double pbuf[2][CH];
   // speculative exact summation (SPEC): boundary tables of spec_exact_sum, per channel
-  __shared__ int sJ[SPEC ? 2 : 1][4][16][16];
+  __shared__ int sJ[2][16][16];
   __shared__ double sX1[2];
+  __shared__ double sA[2][16];  // SPEC: approximate segment sums (the guess of spec_exact_sum)
   __shared__ uint16_t tab[RSQ_LDS_MAX];
 
   const LmsJob job = jobs[blockIdx.x];
@@ -338,18 +305,32 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
   bits &= 0xff;
   for (int i = tid; i < (2 << bits); i += NT) tab[i] = gtab[i];
   for (int i = tid; i < 2 * RL; i += NT) (&ring[0][0])[i] = 0.;
+  if (SPEC)
+    for (int i = tid; i < 2 * TP; i += NT) (&prods[0][0])[i] = 0.;  // chain 15 of the MFMA passes is idle: keep its operands finite
   __syncthreads();
 
-  // per-slot constants
+  // per-slot constants. Carried state: w at [tap], eg at [R*NT + tap], tap = channel*T + i.
   double w[R], eg[R], mu[R];
-  int hoff[R], hsel[R], paddr[R], cs[R];
+  int hoff[R], hsel[R], paddr[R], cs[R], tap[R];
   bool valid[R];
+  const int hseg = tid >> 5, hl = tid & 31;
 #pragma unroll
   for (int r = 0; r < R; r++) {
-    const int g = r * NT + tid;
-    valid[r] = g < 2 * T;
-    const int c = (g >= T) ? 1 : 0, i = g - c * T;
+    int c, i;
+    if constexpr (SPEC) {
+      // half-wave `hseg` owns segment `hseg` of both channels (slots 0..3: channel 0, 4..7: channel 1), lane l its
+      // taps l, 32+l, 64+l, 96+l: a segment's approximate sum is a half-wave reduction
+      c = r >> 2;
+      i = SEG * hseg + 32 * (r & 3) + hl;
+      valid[r] = hseg < NSEG;
+    } else {
+      const int g = r * NT + tid;
+      valid[r] = g < 2 * T;
+      c = (g >= T) ? 1 : 0;
+      i = g - c * T;
+    }
     cs[r] = c;
+    tap[r] = c * T + i;
     int src, lag;
     if (i < S) { src = c; lag = 1 + i; mu[r] = job.mu1; }
     else { const int j = i - S; src = 1 - c; lag = (c == 0 ? 1 : 0) + j; mu[r] = job.mu2; }
@@ -358,9 +339,9 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
     paddr[r] = SPEC ? c * TP + (i / SEG) * SEGP + (i % SEG) : c * TP + i;
     w[r] = 0.; eg[r] = 0.;
     if (!valid[r]) { hsel[r] = 0; hoff[r] = 0; paddr[r] = 0; }
-    if (t0 > 0 && job.state) {  // resume: weights / gradient energies of the previous chunk
-      w[r] = job.state[r * NT + tid];
-      eg[r] = job.state[(R + r) * NT + tid];
+    if (t0 > 0 && job.state && valid[r]) {  // resume: weights / gradient energies of the previous chunk
+      w[r] = job.state[tap[r]];
+      eg[r] = job.state[R * NT + tap[r]];
     }
   }
   if (t0 > 0) {  // history before the chunk comes straight from the stage's input arrays
@@ -398,22 +379,36 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
       __syncthreads();
     }
     // ---- products w[i]*hist[i] (nlms.h:111)
-    double h[R];
+    double h[R], part[2] = {0., 0.};
 #pragma unroll
     for (int r = 0; r < R; r++) {
       h[r] = ring[hsel[r]][(t + hoff[r]) & M];
-      if (valid[r]) (&prods[0][0])[paddr[r]] = w[r] * h[r];
+      const double pr = w[r] * h[r];
+      if (valid[r]) (&prods[0][0])[paddr[r]] = pr;
+      if (SPEC) part[r >> 2] += pr;
+    }
+    if constexpr (SPEC) {
+      // approximate segment sums (tree order: a guess only): 16-lane rows by DPP, then row 0 -> 1 and row 2 -> 3
+#pragma unroll
+      for (int c = 0; c < 2; c++) {
+        double v = row_prefix16(part[c]);
+        int lo = __double2loint(v), hi = __double2hiint(v);
+        lo = __builtin_amdgcn_update_dpp(0, lo, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1 and 3
+        hi = __builtin_amdgcn_update_dpp(0, hi, 0x142, 0xA, 0xF, false);
+        v += __hiloint2double(hi, lo);
+        if (hl == 31 && valid[0]) sA[c][hseg] = v;
+      }
     }
     __syncthreads();
     // ---- pred = 0.; for i: pred += w[i]*hist[i]  -- strict order, on the matrix pipe
     if constexpr (SPEC) {
-      static_assert(T == 1920 && NT >= 512 && SEGP == 122, "SPEC is laid out for the (1280,640) stage, phases on waves 0..7");
+      static_assert(T == NSEG * SEG && NT == 512 && R == 8, "SPEC is laid out for the (1280,640) stage, phases on waves 0..7");
       // waves 0..7: channel = wave & 1, candidate group = wave >> 1, so that the two channels' walkers (waves 0, 1)
       // and each channel's four candidate waves sit on different SIMDs
       const int sc = wave & 1, grp = wave < 8 ? (wave >> 1) : -1;
       long long rounds_ = 0;
-      const double res = spec_exact_sum<16, 30, 122>((uint32_t)(uintptr_t)&prods[sc][0], sJ[sc], &sX1[sc], nullptr, grp, grp == 0, dbg, rounds_);
-      if (grp == 0 && lane == 60) {
+      const double res = spec_exact_sum<NSEG, SEG / 4, SEGP>((uint32_t)(uintptr_t)&prods[sc][0], sJ[sc], &sX1[sc], sA[sc], grp, grp == 0, dbg, rounds_);
+      if (grp == 0 && lane == 16 * ((NSEG - 1) & 3) + 4 * ((NSEG - 1) >> 2)) {
         predv[sc] = res;
         pbuf[sc][t & (CH - 1)] = res;
       }
@@ -453,10 +448,8 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
   if (tend > t0) flush((tend - 1) & ~(CH - 1), tend);
   if (job.state) {
 #pragma unroll
-    for (int r = 0; r < R; r++) {
-      job.state[r * NT + tid] = w[r];
-      job.state[(R + r) * NT + tid] = eg[r];
-    }
+    for (int r = 0; r < R; r++)
+      if (valid[r]) { job.state[tap[r]] = w[r]; job.state[R * NT + tap[r]] = eg[r]; }
   }
 }
 
@@ -467,7 +460,7 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
 // channels in one workgroup) the tap update -- VALU-throughput bound -- has twice the SIMDs, and
 // the serial phases of one channel no longer wait for the other's verification retries.
 //
-// Per sample (3 barriers): products w[i]*hist[i] -> LDS (16 segments of 120, stride 122: bank-conflict-free
+// Per sample (3 barriers): products w[i]*hist[i] -> LDS (15 segments of 128, stride 130: bank-conflict-free
 // MFMA operand reads) | spec_exact_sum (waves 0..3 sum candidates, wave 0 walks and verifies) | update
 // (nlms.h:114-129, all threads). Predictions are buffered in LDS and written out once per 256 samples.
 // ------------------------------------------------------------------------------------------
@@ -476,8 +469,6 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
 #define L1_CH 256
 #define L1_RLO 2048
 #define L1_RLX 1024
-#define L1_SEG 128   // products per segment (32 MFMA steps)
-#define L1_SEGP 130  // segment stride in LDS: the 16 chain lanes of a ds_read_b64 half on 16 different 4-bank groups
 
 // rsq_emul with the integer part folded (argument is eg + 0.001 > 0 or NaN):
 //   index  = bits [23-bits, 23] of the float (top mantissa bits + exponent parity)
@@ -500,7 +491,7 @@ __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs
   __shared__ double ringo[L1_RLO];  // own channel's stage inputs   (taps 0..1279: lags 1..1280)
   __shared__ double ringx[L1_RLX];  // other channel's stage inputs (taps 1280..1919)
   __shared__ double pbuf[CH];
-  __shared__ int sJ[4][16][16];
+  __shared__ int sJ[16][16];
   __shared__ double sX1;
   __shared__ double predv;
   __shared__ uint16_t tab[RSQ_LDS_MAX];

@@ -14,4 +14,6 @@ for seed, off in ((1000, 77175), (1003, 20000)):
     for extra in [int(a) for a in sys.argv[1:]] or [0]:
         os.environ["SACOPT_DBG"] = str(128 + extra)
         q0, q1 = ctx.lms_pair(1280, 640, 1e-5, 5e-6, x0, x1)
-        print(f"seed {seed} dbg {extra}: P2 passes per sample: ch0 {q0[0] / n:.3f}  ch1 {q1[0] / n:.3f}")
+        a0, a1 = int(q0[0]), int(q1[0])
+        print(f"seed {seed} dbg {extra}: P2 passes per sample: ch0 {(a0 & 0xffffffff) / n:.3f}  ch1 {(a1 & 0xffffffff) / n:.3f}"
+              f"   walk iterations per sample (dbg 1024): ch0 {(a0 >> 32) / n:.3f}  ch1 {(a1 >> 32) / n:.3f}")
