@@ -464,8 +464,10 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
 // MFMA operand reads) | spec_exact_sum (waves 0..3 sum candidates, wave 0 walks and verifies) | update
 // (nlms.h:114-129, all threads). Predictions are buffered in LDS and written out once per 256 samples.
 // ------------------------------------------------------------------------------------------
-#define L1_NT 512
-#define L1_R 4
+#ifndef L1_NT
+#define L1_NT 1024
+#endif
+#define L1_R (2048 / L1_NT)
 #define L1_CH 256
 #define L1_RLO 2048
 #define L1_RLX 1024
@@ -521,16 +523,18 @@ __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs
   double *st = job.state ? job.state + c * T : nullptr;
   // Half-wave `seg` (32 threads) owns the 128 taps of segment `seg`, lane l the taps l, 32+l, 64+l, 96+l of it:
   // consecutive lanes read consecutive history values, and a segment's approximate sum is a half-wave reduction.
-  const int seg = tid >> 5, hl = tid & 31;
+  constexpr int HW = NT / 16;  // threads per segment: a half-wave (NT = 512) or a wave (NT = 1024)
+  static_assert(HW * R == SEG, "slots");
+  const int seg = tid / HW, hl = tid % HW;
   int tap[R];
 #pragma unroll
   for (int r = 0; r < R; r++) {
-    const int i = SEG * seg + 32 * r + hl;
+    const int i = SEG * seg + HW * r + hl;
     tap[r] = i;
     valid[r] = seg < NSEG;
     if (i < S) { hb[r] = ringo; hmask[r] = MO; hoff[r] = (-(1 + i)) & MO; mu[r] = job.mu1; }
     else { hb[r] = ringx; hmask[r] = MX; hoff[r] = (-(lagx + (i - S))) & MX; mu[r] = job.mu2; }
-    pa[r] = seg * SEGP + 32 * r + hl;
+    pa[r] = seg * SEGP + HW * r + hl;
     if (!valid[r]) { hb[r] = ringo; hmask[r] = MO; hoff[r] = 0; pa[r] = 0; }
     w[r] = 0.; eg[r] = 0.;
     if (t0 > 0 && st && valid[r]) { w[r] = st[i]; eg[r] = st[4096 + i]; }
@@ -580,7 +584,13 @@ __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs
       hi = __builtin_amdgcn_update_dpp(0, hi, 0x142, 0xA, 0xF, false);
       part += __hiloint2double(hi, lo);
     }
-    if (hl == 31 && valid[0]) sA[seg] = part;
+    if (HW == 64) {
+      int lo = __double2loint(part), hi = __double2hiint(part);
+      lo = __builtin_amdgcn_update_dpp(0, lo, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2 and 3
+      hi = __builtin_amdgcn_update_dpp(0, hi, 0x143, 0xC, 0xF, false);
+      part += __hiloint2double(hi, lo);
+    }
+    if (hl == HW - 1 && valid[0]) sA[seg] = part;
     __syncthreads();
     // ---- pred = 0.; for i: pred += w[i]*hist[i]  -- strict order (spec_exact_sum: waves 0..3 sum candidates, wave 0 verifies)
     const double res = spec_exact_sum<NSEG, SEG / 4, SEGP>((uint32_t)(uintptr_t)&prods[0], sJ, &sX1, sA, wave < 4 ? wave : -1, wave == 0, dbg, rounds);
