@@ -313,14 +313,16 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
   double w[R], eg[R], mu[R];
   int hoff[R], hsel[R], paddr[R], cs[R], tap[R];
   bool valid[R];
-  const int hseg = tid >> 5, hl = tid & 31;
+  // SPEC: a half-wave owns one segment (128 taps, 4 per lane). NT = 512: of both channels (slots 0..3 channel 0, 4..7
+  // channel 1); NT = 1024: half-waves 0..15 channel 0, 16..31 channel 1.
+  constexpr bool BOTH = (NT == 512);
+  const int hseg = (tid >> 5) & 15, hl = tid & 31, hch = tid >> 9;
 #pragma unroll
   for (int r = 0; r < R; r++) {
     int c, i;
     if constexpr (SPEC) {
-      // half-wave `hseg` owns segment `hseg` of both channels (slots 0..3: channel 0, 4..7: channel 1), lane l its
-      // taps l, 32+l, 64+l, 96+l: a segment's approximate sum is a half-wave reduction
-      c = r >> 2;
+      // lane l: taps l, 32+l, 64+l, 96+l of the segment: its approximate sum is a half-wave reduction
+      c = BOTH ? (r >> 2) : hch;
       i = SEG * hseg + 32 * (r & 3) + hl;
       valid[r] = hseg < NSEG;
     } else {
@@ -385,24 +387,24 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
       h[r] = ring[hsel[r]][(t + hoff[r]) & M];
       const double pr = w[r] * h[r];
       if (valid[r]) (&prods[0][0])[paddr[r]] = pr;
-      if (SPEC) part[r >> 2] += pr;
+      if (SPEC) part[BOTH ? (r >> 2) : 0] += pr;
     }
     if constexpr (SPEC) {
       // approximate segment sums (tree order: a guess only): 16-lane rows by DPP, then row 0 -> 1 and row 2 -> 3
 #pragma unroll
-      for (int c = 0; c < 2; c++) {
+      for (int c = 0; c < (BOTH ? 2 : 1); c++) {
         double v = row_prefix16(part[c]);
         int lo = __double2loint(v), hi = __double2hiint(v);
         lo = __builtin_amdgcn_update_dpp(0, lo, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1 and 3
         hi = __builtin_amdgcn_update_dpp(0, hi, 0x142, 0xA, 0xF, false);
         v += __hiloint2double(hi, lo);
-        if (hl == 31 && valid[0]) sA[c][hseg] = v;
+        if (hl == 31 && valid[0]) sA[BOTH ? c : hch][hseg] = v;
       }
     }
     __syncthreads();
     // ---- pred = 0.; for i: pred += w[i]*hist[i]  -- strict order, on the matrix pipe
     if constexpr (SPEC) {
-      static_assert(T == NSEG * SEG && NT == 512 && R == 8, "SPEC is laid out for the (1280,640) stage, phases on waves 0..7");
+      static_assert(T == NSEG * SEG && NT * R == 4096 && (NT == 512 || NT == 1024), "SPEC is laid out for the (1280,640) stage, phases on waves 0..7");
       // waves 0..7: channel = wave & 1, candidate group = wave >> 1, so that the two channels' walkers (waves 0, 1)
       // and each channel's four candidate waves sit on different SIMDs
       const int sc = wave & 1, grp = wave < 8 ? (wave >> 1) : -1;
@@ -1273,6 +1275,9 @@ extern "C" int sacopt_launch_lms(int S, int D, const LmsJob *jobs, int njobs, co
   if (S == 1280 && D == 640) {
     if (sacopt_lms_variant(S, D, njobs, bits)) hipLaunchKernelGGL(k_lms1c, dim3(2 * njobs), dim3(L1_NT), 0, st, jobs, tab, bits);
     else if ((bits >> 8) & 8) hipLaunchKernelGGL((k_lms<1280, 640, 1024, 4, 2048, false>), dim3(njobs), dim3(1024), 0, st, jobs, tab, bits);
+    // 1024 threads are faster for a chain alone (9.4k against 10.0k cycles per sample) but slower in the optimizer's
+    // rounds, where the follower stages want room on the same CUs (optimize 571 against 526 ms): A/B switch only
+    else if ((bits >> 8) & 4096) hipLaunchKernelGGL((k_lms<1280, 640, 1024, 4, 2048, true>), dim3(njobs), dim3(1024), 0, st, jobs, tab, bits);
     else hipLaunchKernelGGL((k_lms<1280, 640, 512, 8, 2048, true>), dim3(njobs), dim3(512), 0, st, jobs, tab, bits);
   }
   else if (S == 256 && D == 128) hipLaunchKernelGGL((k_lms<256, 128, 256, 3, 1024, false>), dim3(njobs), dim3(256), 0, st, jobs, tab, bits);
