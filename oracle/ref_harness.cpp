@@ -105,6 +105,35 @@ void ref_predict_stereo_frame(int profile, const double *coefs, int ncoef, const
   }
 }
 
+// UnpredictStereoFrame(profile, 0, 1, n) (codec.cpp:216-235) on residuals error[ch][0..n).
+// used0/used1: NULL = framestats[ch].enc_mapped false, else Remap::usedl[0..scale] then usedh[0..scale] (bytes);
+// minmax = {minval0, maxval0, minval1, maxval1} = framestats[ch].minval/maxval (read by StereoHigh::Unpredict only;
+// the reference's decoder never sets them, the caller does).
+void ref_unpredict_stereo_frame(int profile, const double *coefs, int ncoef, const int32_t *e0, const int32_t *e1, int n,
+                                const unsigned char *used0, const unsigned char *used1, const int32_t *minmax,
+                                int32_t *v0, int32_t *v1) {
+  CoutMute mute;
+  FrameCoder fc(2, n, profile);
+  fc.SetNumSamples(n);
+  const unsigned char *used[2] = {used0, used1};
+  for (int ch = 0; ch < 2; ch++) {
+    auto &fs = fc.framestats[ch];
+    fs.enc_mapped = used[ch] != nullptr;
+    fs.mymap.Reset();
+    if (used[ch]) {
+      const int sc = fs.mymap.scale;
+      for (int i = 0; i <= sc; i++) { fs.mymap.usedl[i] = used[ch][i] != 0; fs.mymap.usedh[i] = used[ch][sc + 1 + i] != 0; }
+    }
+    fs.minval = minmax ? minmax[2 * ch] : INT32_MIN;
+    fs.maxval = minmax ? minmax[2 * ch + 1] : INT32_MAX;
+  }
+  for (int i = 0; i < n; i++) { fc.error[0][i] = e0[i]; fc.error[1][i] = e1[i]; }
+  SacProfile p = fc.baseprofile;
+  set_coefs(p, coefs, ncoef);
+  fc.UnpredictStereoFrame(p, 0, 1, n);
+  for (int i = 0; i < n; i++) { v0[i] = fc.samples[0][i]; v1[i] = fc.samples[1][i]; }
+}
+
 // CostGolomb::Calc with the carried running mean exposed (state_inout).
 double ref_cost_golomb(const int32_t *buf, int n, double *state_inout) {
   CostGolomb c;

@@ -599,6 +599,80 @@ int oracle_predict_stereo_frame(int profile, const double *coefs, const int32_t 
   return 0;
 }
 
+/* ------------------------------------------------------------------ UnpredictStereoFrame (src/codec.cpp:216-235) */
+static int32_t remap_unmap(const remap_t *r, int32_t pred, int32_t merr) { /* map.cpp:154-168 */
+  int sgn = 1;
+  if (merr == 0) return 0;
+  if (merr < 0) { merr = -merr; sgn = -1; }
+  int err = 1, terr = 0;
+  while (1) {
+    if (remap_is_used(r, pred + (sgn * err))) terr++;
+    if (terr == merr) break;
+    if (err > 4 * RSCALE) break; /* the reference loops forever on a stream no encoder writes; stop */
+    err++;
+  }
+  return sgn * err;
+}
+static int32_t clamp_i32(int32_t v, int32_t lo, int32_t hi) { return v < lo ? lo : v > hi ? hi : v; } /* global.h:16 */
+
+/* Unpredict(err0,err1,&val0,&val1) + Update(): profile.cpp:34-43 (fast: no unmap, no clamp),
+ * :89-100 (normal: unmap), :161-174 (high: clamp to [minval,maxval], then unmap) */
+static void stereo_unstep(stereo_t *s, int32_t e0, int32_t e1, const remap_t *map0, const remap_t *map1,
+                          const int32_t *minval, const int32_t *maxval, int32_t *v0, int32_t *v1) {
+  if (s->type == 0) {
+    double pa = lpc2_predict(&s->lpc2[0], s->x[1]);
+    *v0 = (int32_t)(e0 + round(pa));
+    lpc2_update(&s->lpc2[0], *v0);
+    s->x[0] = *v0;
+    double pb = lpc2_predict(&s->lpc2[1], s->x[0]);
+    *v1 = (int32_t)(e1 + round(pb));
+    lpc2_update(&s->lpc2[1], *v1);
+    s->x[1] = *v1;
+  } else {
+    int32_t p0 = (int32_t)round(cascade_predict(s, 0, 1));
+    if (s->type == 2) p0 = clamp_i32(p0, minval[0], maxval[0]);
+    if (map0) e0 = remap_unmap(map0, p0, e0);
+    *v0 = e0 + p0;
+    cascade_calc_error(s, 0, *v0);
+    int32_t p1 = (int32_t)round(cascade_predict(s, 1, 0));
+    if (s->type == 2) p1 = clamp_i32(p1, minval[1], maxval[1]);
+    if (map1) e1 = remap_unmap(map1, p1, e1);
+    *v1 = e1 + p1;
+    cascade_calc_error(s, 1, *v1);
+    cascade_update(s);
+  }
+}
+
+/* used0/used1: NULL = channel not mapped (enc_mapped false), else 2*(RSCALE+1) bytes: usedl[0..RSCALE] then usedh[0..RSCALE]
+ * (map.h: Remap::usedl/usedh as the MapEncoder delivers them). minmax = {minval0, maxval0, minval1, maxval1} (high profile). */
+int oracle_unpredict_stereo_frame(int profile, const double *coefs, const int32_t *e0, const int32_t *e1, int n,
+                                  const unsigned char *used0, const unsigned char *used1, const int32_t *minmax,
+                                  int32_t *v0, int32_t *v1) {
+  double base[8 * 3], c[8];
+  int nc = oracle_base_profile(profile, base);
+  if (!nc) return 1;
+  for (int i = 0; i < nc; i++) c[i] = coefs ? coefs[i] : base[3 * i + 2];
+  stereo_t *sp = stereo_new(profile, c);
+  remap_t *map0 = 0, *map1 = 0;
+  if (used0) { map0 = (remap_t *)malloc(sizeof(remap_t)); memcpy(map0->usedl, used0, RSCALE + 1); memcpy(map0->usedh, used0 + RSCALE + 1, RSCALE + 1); }
+  if (used1) { map1 = (remap_t *)malloc(sizeof(remap_t)); memcpy(map1->usedl, used1, RSCALE + 1); memcpy(map1->usedh, used1 + RSCALE + 1, RSCALE + 1); }
+  int32_t mn[2] = {minmax ? minmax[0] : INT32_MIN, minmax ? minmax[2] : INT32_MIN};
+  int32_t mx[2] = {minmax ? minmax[1] : INT32_MAX, minmax ? minmax[3] : INT32_MAX};
+  for (int i = 0; i < n; i++) stereo_unstep(sp, e0[i], e1[i], map0, map1, mn, mx, &v0[i], &v1[i]);
+  stereo_free(sp);
+  free(map0); free(map1);
+  return 0;
+}
+
+/* Remap::Analyse as the decoder's tables: 2*(RSCALE+1) bytes, usedl then usedh (map.cpp:111-130) */
+void oracle_remap_tables(const int32_t *src, int n, unsigned char *used) {
+  remap_t *r = (remap_t *)malloc(sizeof(remap_t));
+  remap_analyse(r, src, n);
+  memcpy(used, r->usedl, RSCALE + 1);
+  memcpy(used + RSCALE + 1, r->usedh, RSCALE + 1);
+  free(r);
+}
+
 /* ------------------------------------------------------------------ cost functions (src/codec.cpp:302-339) */
 double oracle_cost_meanrms(const int32_t *buf, int n) { /* codec.cpp:302-312 */
   if (n) {

@@ -54,6 +54,13 @@ void oracle_lpc3_pair(double alpha, const int32_t *s0, const int32_t *s1, int n,
 void oracle_rls_run(int n, double alpha, const double *pv, const double *val, int len, double *p);
 void oracle_cascade_trace(int profile, const double *coefs, const int32_t *s0, const int32_t *s1,
                           int n, double *p_out, double *v_out, int32_t *e0, int32_t *e1);
+/* FrameCoder::UnpredictStereoFrame (src/codec.cpp:216-235) with Stereo{Fast,Normal,High}::Unpredict
+ * (src/profile.cpp:34-43, 89-100, 161-174) and Remap::Unmap (src/coder/map.cpp:154-168).
+ * used0/used1: NULL = not mapped, else usedl[0..32768] then usedh[0..32768] as bytes; minmax: {min0,max0,min1,max1} or NULL. */
+int oracle_unpredict_stereo_frame(int profile, const double *coefs, const int32_t *e0, const int32_t *e1, int n,
+                                  const unsigned char *used0, const unsigned char *used1, const int32_t *minmax,
+                                  int32_t *v0, int32_t *v1);
+void oracle_remap_tables(const int32_t *src, int n, unsigned char *used);
 void oracle_remap_map(const int32_t *src, int n, const int32_t *pred, const int32_t *err, int m,
                       int32_t *out);
 

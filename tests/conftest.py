@@ -21,6 +21,11 @@ def golden():
 
 
 @pytest.fixture(scope="session")
+def golden_unpredict():
+    return dict(np.load(os.path.join(HERE, "golden", "golden_unpredict.npz"), allow_pickle=False))
+
+
+@pytest.fixture(scope="session")
 def rsqrt_table():
     d = np.load(os.path.join(HERE, "golden", "rsqrt_table.npz"), allow_pickle=False)
     return d["tab"].astype(np.float32), int(d["bits"])

@@ -1,7 +1,7 @@
 """Generate tests/golden/*.npz from the REAL reference (oracle/_ref/libsacref.so).
 
 Run in the build container only (needs /root/reference to build oracle/_ref):
-    make -C oracle ref && python tests/golden/make_golden.py
+    make -C oracle ref && python tests/golden/make_golden.py && python tests/golden/make_golden.py unpredict
 The fixtures are data only: seeded synthetic inputs (re-generated from sac_amd.synth at test
 time, and also stored) and the reference's outputs. They pin the behaviour of the x86
 `rsqrtss` of the CPU they were generated on (Intel Xeon here) -- the probed table travels with
@@ -94,5 +94,43 @@ def main():
     print("wrote", len(out), "arrays")
 
 
+def main_unpredict():
+    """tests/golden/golden_unpredict.npz: FrameCoder::UnpredictStereoFrame (codec.cpp:216-235) of the reference."""
+    ref = Ref()
+    out = {}
+    u2s = lambda u: np.where(u & 1, (u + 1) // 2, -(u // 2)).astype(np.int32)
+    L, R = stereo_clip(41, 3000)
+    Ls, Rs = (L // 8 * 8).astype(np.int32), (R // 8 * 8 + 3).astype(np.int32)  # sparse value grid: the map acts
+    out["L"], out["R"], out["Ls"], out["Rs"] = L, R, Ls, Rs
+    orc = Oracle()
+    out["used0"], out["used1"] = orc.remap_tables(Ls), orc.remap_tables(Rs)
+    rs = np.random.RandomState(42)
+    g0 = rs.randint(-200, 200, 1500).astype(np.int32); g1 = rs.randint(-50, 50, 1500).astype(np.int32)
+    out["g0"], out["g1"] = g0, g1
+    out["mm"] = np.array([-300, 200, -100, 400], np.int32)
+    out["coefs2"] = np.array([0.99, 2e-5, 1e-5, 3e-4, 2e-4, 2e-3, 0.02, 0.999])
+    for prof in (0, 1, 2):
+        d = ref.predict(prof, L, R)
+        out[f"e{prof}_0"], out[f"e{prof}_1"] = d["e0"], d["e1"]
+        v = ref.unpredict(prof, d["e0"], d["e1"])
+        assert np.array_equal(v[0], L) and np.array_equal(v[1], R)
+        out[f"v{prof}_0"], out[f"v{prof}_1"] = v
+        v = ref.unpredict(prof, g0, g1)  # residuals no encoder wrote
+        out[f"vg{prof}_0"], out[f"vg{prof}_1"] = v
+        if prof:
+            d = ref.predict(prof, Ls, Rs, maps=True)
+            out[f"m{prof}_0"], out[f"m{prof}_1"] = u2s(d["m0"]), u2s(d["m1"])
+            v = ref.unpredict(prof, out[f"m{prof}_0"], out[f"m{prof}_1"], used0=out["used0"], used1=out["used1"])
+            assert np.array_equal(v[0], Ls) and np.array_equal(v[1], Rs)
+            out[f"vm{prof}_0"], out[f"vm{prof}_1"] = v
+    d = ref.predict(2, L, R)
+    v = ref.unpredict(2, d["e0"], d["e1"], minmax=out["mm"])  # narrow clamp (profile.cpp:163,170)
+    out["vc2_0"], out["vc2_1"] = v
+    v = ref.unpredict(2, g0, g1, coefs=out["coefs2"])
+    out["vk2_0"], out["vk2_1"] = v
+    np.savez_compressed(os.path.join(HERE, "golden_unpredict.npz"), **out)
+    print("wrote", len(out), "arrays")
+
+
 if __name__ == "__main__":
-    main()
+    main_unpredict() if sys.argv[1:] == ["unpredict"] else main()

@@ -125,6 +125,24 @@ class _Lib:
             f(C.c_int(profile), _ptr(cf), _ptr(s0), _ptr(s1), C.c_int(n), _ptr(p), _ptr(v), _ptr(e0), _ptr(e1))
         return p, v, e0, e1
 
+    def unpredict(self, profile, e0, e1, coefs=None, used0=None, used1=None, minmax=None):
+        """UnpredictStereoFrame: residuals (mapped where used* is given) -> samples."""
+        e0 = np.ascontiguousarray(e0, dtype=np.int32); e1 = np.ascontiguousarray(e1, dtype=np.int32)
+        n = len(e0)
+        v0 = np.zeros(n, np.int32); v1 = np.zeros(n, np.int32)
+        cf = None if coefs is None else np.ascontiguousarray(coefs, dtype=np.float64)
+        u0 = None if used0 is None else np.ascontiguousarray(used0, dtype=np.uint8)
+        u1 = None if used1 is None else np.ascontiguousarray(used1, dtype=np.uint8)
+        mm = None if minmax is None else np.ascontiguousarray(minmax, dtype=np.int32)
+        f = getattr(self.lib, self.pre + "unpredict_stereo_frame")
+        f.restype = None if self.pre == "ref_" else C.c_int
+        if self.pre == "ref_":
+            f(C.c_int(profile), _ptr(cf), C.c_int(0 if cf is None else len(cf)), _ptr(e0), _ptr(e1), C.c_int(n),
+              _ptr(u0), _ptr(u1), _ptr(mm), _ptr(v0), _ptr(v1))
+        else:
+            f(C.c_int(profile), _ptr(cf), _ptr(e0), _ptr(e1), C.c_int(n), _ptr(u0), _ptr(u1), _ptr(mm), _ptr(v0), _ptr(v1))
+        return v0, v1
+
     def remap_map(self, src, pred, err):
         src = np.ascontiguousarray(src, dtype=np.int32)
         pred = np.ascontiguousarray(pred, dtype=np.int32); err = np.ascontiguousarray(err, dtype=np.int32)
@@ -160,6 +178,13 @@ class Oracle(_Lib):
 
     def cholesky_kat(self):
         return bool(self.lib.oracle_cholesky_kat())
+
+    def remap_tables(self, src):
+        """Remap::Analyse of a frame as the decoder's tables: usedl[0..32768] then usedh[0..32768] (bytes)."""
+        src = np.ascontiguousarray(src, dtype=np.int32)
+        used = np.zeros(2 * 32769, np.uint8)
+        self.lib.oracle_remap_tables(_ptr(src), C.c_int(len(src)), _ptr(used))
+        return used
 
     def optimize(self, profile, s0, s1, prof=None, ncoef_loop=8, max_rows=128):
         s0 = np.ascontiguousarray(s0, dtype=np.int32); s1 = np.ascontiguousarray(s1, dtype=np.int32)

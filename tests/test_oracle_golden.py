@@ -93,3 +93,25 @@ def test_ragged_and_empty(oracle):
     assert len(d["e0"]) == 0
     d = oracle.predict(2, L, R, frm=49, n=1)
     assert d["e0"][0] == L[49] and d["e1"][0] == R[49]  # fresh state predicts 0
+
+
+def unpredict_cases(g):
+    """(name, profile, residuals, keyword arguments, expected samples) of tests/golden/golden_unpredict.npz"""
+    for prof in (0, 1, 2):
+        yield f"plain{prof}", prof, (g[f"e{prof}_0"], g[f"e{prof}_1"]), {}, (g[f"v{prof}_0"], g[f"v{prof}_1"])
+        yield f"garbage{prof}", prof, (g["g0"], g["g1"]), {}, (g[f"vg{prof}_0"], g[f"vg{prof}_1"])
+        if prof:
+            yield (f"mapped{prof}", prof, (g[f"m{prof}_0"], g[f"m{prof}_1"]), dict(used0=g["used0"], used1=g["used1"]),
+                   (g[f"vm{prof}_0"], g[f"vm{prof}_1"]))
+    e = (g["e2_0"], g["e2_1"])
+    yield "clamp2", 2, e, dict(minmax=g["mm"]), (g["vc2_0"], g["vc2_1"])
+    yield "coefs2", 2, (g["g0"], g["g1"]), dict(coefs=g["coefs2"]), (g["vk2_0"], g["vk2_1"])
+
+
+def test_unpredict_stereo_frame(oracle, golden_unpredict):
+    # FrameCoder::UnpredictStereoFrame (codec.cpp:216-235), Remap::Unmap (map.cpp:154-168)
+    g = golden_unpredict
+    for name, prof, e, kw, want in unpredict_cases(g):
+        v = oracle.unpredict(prof, *e, **kw)
+        assert np.array_equal(v[0], want[0]) and np.array_equal(v[1], want[1]), name
+    assert np.array_equal(g["v2_0"], g["L"]) and np.array_equal(g["vm1_1"], g["Rs"])  # the fixtures are round trips

@@ -103,3 +103,66 @@ def test_degenerate_inputs(pair):
             a = o.predict(prof, L, R, maps=True); b = r.predict(prof, L, R, maps=True)
             for k in a:
                 assert np.array_equal(a[k], b[k]), (name, prof, k)
+
+
+def _sparse_clip(seed, n):
+    # samples on a coarse value grid: most values unused, so Remap::Map changes the residuals
+    L, R = stereo_clip(seed, n)
+    return (L // 8 * 8).astype(np.int32), (R // 8 * 8 + 3).astype(np.int32)
+
+
+@pytest.mark.parametrize("prof,seed,n", [(0, 31, 4000), (1, 32, 3000), (2, 33, 2500)])
+def test_unpredict_plain(pair, prof, seed, n):
+    # FrameCoder::UnpredictStereoFrame (codec.cpp:216-235): oracle == reference, and decode(encode(x)) == x
+    o, r = pair
+    L, R = stereo_clip(seed, n)
+    enc = o.predict(prof, L, R)
+    a = o.unpredict(prof, enc["e0"], enc["e1"])
+    b = r.unpredict(prof, enc["e0"], enc["e1"])
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert np.array_equal(a[0], L) and np.array_equal(a[1], R)
+
+
+@pytest.mark.parametrize("prof,seed,n", [(1, 34, 2500), (2, 35, 2000)])
+def test_unpredict_mapped(pair, prof, seed, n):
+    # enc_mapped channels: residuals go through Remap::Unmap (map.cpp:154-168); one channel mapped, then both
+    o, r = pair
+    L, R = _sparse_clip(seed, n)
+    enc = o.predict(prof, L, R, maps=True)
+    u2s = lambda u: np.where(u & 1, (u + 1) // 2, -(u // 2)).astype(np.int32)  # inverse of S2U (utils.h:56-61)
+    m0, m1 = u2s(enc["m0"]), u2s(enc["m1"])
+    assert not np.array_equal(m0, enc["e0"])  # the map does something on this input
+    t0, t1 = o.remap_tables(L), o.remap_tables(R)
+    for kw, ee in ((dict(used0=t0), (m0, enc["e1"])), (dict(used0=t0, used1=t1), (m0, m1))):
+        a = o.unpredict(prof, *ee, **kw)
+        b = r.unpredict(prof, *ee, **kw)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        assert np.array_equal(a[0], L) and np.array_equal(a[1], R)
+
+
+def test_unpredict_high_clamp(pair):
+    # StereoHigh::Unpredict clamps the prediction to framestats[ch].minval/maxval (profile.cpp:163,170); the encoder
+    # does not, so a narrow range decodes to something else than the input -- the oracle must follow the reference
+    o, r = pair
+    L, R = stereo_clip(36, 2000)
+    enc = o.predict(2, L, R)
+    mm = [-300, 200, -100, 400]
+    a = o.unpredict(2, enc["e0"], enc["e1"], minmax=mm)
+    b = r.unpredict(2, enc["e0"], enc["e1"], minmax=mm)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert not np.array_equal(a[0], L)
+    wide = [int(L.min()), int(L.max()), int(R.min()), int(R.max())]
+    a = o.unpredict(2, enc["e0"], enc["e1"], minmax=wide)
+    b = r.unpredict(2, enc["e0"], enc["e1"], minmax=wide)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_unpredict_coefs_and_garbage_residuals(pair):
+    # non-default coefficients; residuals that no encoder produced (decoder state diverges, still deterministic)
+    o, r = pair
+    rs = np.random.RandomState(9)
+    e0 = rs.randint(-200, 200, 1500).astype(np.int32); e1 = rs.randint(-50, 50, 1500).astype(np.int32)
+    for prof, cf in ((0, [0.993]), (1, [0.997, 3e-4, 2e-4, 2e-3, 0.02, 0.999]), (2, [0.99, 2e-5, 1e-5, 3e-4, 2e-4, 2e-3, 0.02, 0.999])):
+        a = o.unpredict(prof, e0, e1, coefs=cf)
+        b = r.unpredict(prof, e0, e1, coefs=cf)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), prof
