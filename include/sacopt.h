@@ -103,6 +103,26 @@ int sacopt_optimize_frames(sacopt_ctx *ctx, int profile, int nframes, const saco
 int sacopt_encode_frames(sacopt_ctx *ctx, int profile, int nframes, const sacopt_frame *frames,
                          const double *prof, int ncoef_loop, double *best, sacopt_residuals *out);
 
+/* ---- FrameCoder::UnpredictStereoFrame(profile, 0, 1, numsamples)   src/codec.cpp:216-235 ------ */
+/* Decoder-side cascade: Stereo{Fast,Normal,High}::Unpredict + Update (src/profile.cpp:34-43,
+ * 89-111, 161-186) with Remap::Unmap (src/coder/map.cpp:154-168) for channels coded mapped. One frame of one
+ * stereo pair as FrameCoder::Decode leaves it (src/codec.cpp:510-528): */
+typedef struct {
+  const int32_t *e0, *e1;  /* error[ch][0..numsamples): residuals, mapped where used{0,1} != NULL (host or device)   */
+  int32_t *v0, *v1;        /* out: samples[ch][0..numsamples) (host or device)                                      */
+  int32_t numsamples;
+  const uint8_t *used0, *used1; /* NULL = framestats[ch].enc_mapped false; else the channel's Remap tables as the
+                                   MapEncoder decoded them: usedl[0..32768] then usedh[0..32768], one byte each (HOST) */
+  int32_t minval[2], maxval[2]; /* framestats[ch].minval/maxval: StereoHigh::Unpredict clamps its prediction to
+                                   them (src/profile.cpp:163,170; the encoder does not clamp). Other profiles ignore them. */
+} sacopt_dec_frame;
+/* coefs: nframes x ncoef predictor parameters (NULL = base profile, what DecodeFile uses, src/codec.cpp:463-478).
+ * Fresh predictor state per frame; frames are decoded concurrently, one workgroup each. A mapped residual that asks
+ * for more used values than the table holds (no encoder writes one; the reference would not terminate) decodes as
+ * a step of +-131073. */
+int sacopt_unpredict_stereo_frames(sacopt_ctx *ctx, int profile, int nframes, const sacopt_dec_frame *frames,
+                                   const double *coefs);
+
 /* ---- CostGolomb::Calc / CostMeanRMS::Calc on caller-supplied residuals (src/codec.cpp:302-339) - */
 int sacopt_cost_golomb(sacopt_ctx *ctx, const int32_t *buf, int n, double *state_inout, double *cost);
 int sacopt_cost_meanrms(sacopt_ctx *ctx, const int32_t *buf, int n, double *cost);

@@ -79,4 +79,16 @@ struct MapJob {
   int32_t numsamples, n;
 };
 
+// UnpredictStereoFrame (src/codec.cpp:216-235) for one frame.
+#define UN_MAPW 2052  // 32-bit words per table of the decoder's used-value map (65537 bits = 2049 words, padded)
+struct UnJob {
+  const int32_t *e[2];     // residuals error[ch][0..n) as the entropy decoder delivers them (mapped where map[ch] != NULL)
+  int32_t *v[2];           // out: samples
+  const uint32_t *map[2];  // NULL = channel not mapped (enc_mapped false); else [2*UN_MAPW]: bitmap of used values
+                           // (bit v+32768, value 0 always set) then the number of set bits in the words before each word
+  int32_t n;
+  int32_t minval[2], maxval[2];  // StereoHigh::Unpredict clamps its prediction to these (profile.cpp:163,170)
+  double coef[8];
+};
+
 #endif

@@ -37,6 +37,12 @@ __device__ __forceinline__ double rsq_emul(double a, const uint16_t *tab, int bi
   return (double)__uint_as_float(tb);
 }
 
+// (int32_t)x as the reference's x86-64 build converts (cvttsd2si): anything outside int32, NaN included, becomes
+// INT32_MIN (the GPU's own conversion saturates). Only garbage residuals on the decoder side get there.
+__device__ __forceinline__ int32_t cvt_i32_x86(double x) {
+  return (x < 2147483648.0 && x > -2147483649.0) ? (int32_t)x : (int32_t)0x80000000;
+}
+
 __device__ __forceinline__ double bcast(double v, int srclane) {
   int lo = __double2loint(v), hi = __double2hiint(v);
   lo = __builtin_amdgcn_readlane(lo, srclane);
@@ -714,15 +720,9 @@ __global__ __launch_bounds__(384) void k_cov(const LpcJob *__restrict__ jobs) {
 // lane 24 carries CalcY (:37-46) as an extra row. Each scalar's inner sum runs in the
 // reference's k order. FAST: full-order Solve(b,x) only, regp = 0; else all orders, regp = 500.
 template <bool FAST>
-__global__ __launch_bounds__(64) void k_chol(const LpcJob *__restrict__ jobs) {
+__device__ __forceinline__ bool chol_wave(const double *snap, double *solo, int lane) {  // true = "matrix indefinit", solo untouched
   constexpr int N = LPC_N;
   constexpr double REGP = FAST ? 0. : 500.;
-  const LpcJob &job = jobs[blockIdx.y >> 1];
-  const int ch = blockIdx.y & 1, k = job.t0 / (FAST ? 32 : 8) + blockIdx.x, lane = threadIdx.x;
-  if (k >= job.nsnap) return;
-  const double *snap = (ch ? job.snap[1] : job.snap[0]) + (size_t)k * LPC_SNAP;
-  double *solo = (ch ? job.sol[1] : job.sol[0]) + (size_t)k * (FAST ? N : LPC_TRI);
-  int32_t *failo = (ch ? job.fail[1] : job.fail[0]) + k;
   double m[N];
   const int row = lane <= N ? lane : 0;
 #pragma unroll
@@ -747,8 +747,7 @@ __global__ __launch_bounds__(64) void k_chol(const LpcJob *__restrict__ jobs) {
       } else fail = true;  // "matrix indefinit": the previous solution stays in force (lpc.h:216-218)
     }
   }
-  if (lane == 0) *failo = fail ? 1 : 0;
-  if (fail) return;
+  if (fail) return true;
   double sol[N];
 #pragma unroll
   for (int i = 0; i < N; i++) sol[i] = 0.;
@@ -782,6 +781,18 @@ __global__ __launch_bounds__(64) void k_chol(const LpcJob *__restrict__ jobs) {
       for (int i = 0; i < N; i++) solo[i] = sol[i];
     }
   }
+  return false;
+}
+template <bool FAST>
+__global__ __launch_bounds__(64) void k_chol(const LpcJob *__restrict__ jobs) {
+  const LpcJob &job = jobs[blockIdx.y >> 1];
+  const int ch = blockIdx.y & 1, k = job.t0 / (FAST ? 32 : 8) + blockIdx.x, lane = threadIdx.x;
+  if (k >= job.nsnap) return;
+  const double *snap = (ch ? job.snap[1] : job.snap[0]) + (size_t)k * LPC_SNAP;
+  double *solo = (ch ? job.sol[1] : job.sol[0]) + (size_t)k * (FAST ? LPC_N : LPC_TRI);
+  int32_t *failo = (ch ? job.fail[1] : job.fail[0]) + k;
+  const bool fail = chol_wave<FAST>(snap, solo, lane);
+  if (lane == 0) *failo = fail ? 1 : 0;
 }
 
 // index of the snapshot whose solution is in force when predicting sample t (-1: none yet)
@@ -887,7 +898,7 @@ __global__ __launch_bounds__(256) void k_pred2(const LpcJob *__restrict__ jobs) 
     const double *sol = (ch ? job.sol[1] : job.sol[0]) + (size_t)k * LPC_N;
     for (int i = 0; i < LPC_N; i++) p += sol[i] * lpc_hist(own, oth, lagb, i, t);
   }
-  const int32_t e = (int32_t)((double)own[t] - round(p));
+  const int32_t e = cvt_i32_x86((double)own[t] - round(p));
   const int32_t ue = s2u(e);
   int32_t *eo = ch ? job.e[1] : job.e[0], *uo = ch ? job.u[1] : job.u[0];
   if (eo) eo[t] = e;
@@ -981,7 +992,7 @@ __global__ __launch_bounds__(64) void k_mix(const MixJob *__restrict__ jobs, int
       double p = 0.;
 #pragma unroll
       for (int k = 0; k < NS; k++) p += h[k] * w[k];  // RLS::Predict (rls.cpp:67-72)
-      const int32_t q = (int32_t)round(cp0 + p);
+      const int32_t q = cvt_i32_x86(round(cp0 + p));
       const int32_t e = v - q;
       const int32_t ue = s2u(e);
       if (writer) {
@@ -1252,6 +1263,8 @@ __global__ void k_map_apply(const MapJob *jobs) {  // Remap::Map + S2U + running
   for (int o = 32; o; o >>= 1) { const int t = __shfl_xor(mx, o); mx = t > mx ? t : mx; }
   if ((threadIdx.x & 63) == 0 && mx > 0) atomicMax(job.mmax, mx);
 }
+
+#include "unpredict.h"
 
 // ------------------------------------------------------------------------------------------
 // host-callable launchers (sacopt.cpp is compiled by the host compiler pass of the same TU set)

@@ -31,6 +31,7 @@ int sacopt_launch_cost_par(const CostJob *jobs, int njobs, int nbuf, const int *
 int sacopt_launch_meanrms(const int32_t *e, int n, double *out, hipStream_t st);
 int sacopt_launch_rls(int ns, const double *pv, const double *val, int len, double alpha, double *p, hipStream_t st);
 int sacopt_launch_map(const MapJob *jobs, int njobs, int max_numsamples, int max_n, hipStream_t st);
+int sacopt_launch_unpredict(int type, const UnJob *jobs, int njobs, const uint16_t *tab, int bits, hipStream_t st);
 }
 
 static thread_local std::string g_create_error;
@@ -323,6 +324,15 @@ static int upload(sacopt_ctx *c, const std::vector<T> &h, T **d) {
   *d = arena_alloc<T>(c, h.size() ? h.size() : 1);
   if (!*d) { c->err = "device arena exhausted"; return 1; }
   if (h.size()) HIPCK(c, hipMemcpyAsync(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, c->st));
+  return 0;
+}
+template <class T>
+static int to_dev(sacopt_ctx *c, const T *src, size_t count, const T **out) {
+  if (is_device_ptr(src)) { *out = src; return 0; }
+  T *p = arena_alloc<T>(c, count);
+  if (!p) { c->err = "device arena exhausted"; return 1; }
+  HIPCK(c, hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, c->st));
+  *out = p;
   return 0;
 }
 static int begin_call(sacopt_ctx *c) {
@@ -1221,6 +1231,87 @@ extern "C" int sacopt_encode_frames(sacopt_ctx *c, int profile, int nframes, con
   return emit_outputs(c, pd, fr, chains, out);
 }
 
+// ------------------------------------------------------------------------------------------ UnpredictStereoFrame
+// Decoder's used-value tables (Remap::usedl/usedh, src/coder/map.h) -> bitmap over the values -32768..32768 (bit v+32768;
+// value 0 counts as used, map.cpp:138) followed by the number of set bits in the words before each word.
+static void build_unmap_table(const uint8_t *used, uint32_t *out) {
+  memset(out, 0, 2 * UN_MAPW * sizeof(uint32_t));
+  const uint8_t *usedl = used, *usedh = used + 32769;
+  auto set = [&](int v) { const unsigned x = (unsigned)(v + 32768); out[x >> 5] |= 1u << (x & 31); };
+  set(0);
+  for (int v = 1; v <= 32768; v++) {
+    if (usedh[v]) set(v);
+    if (usedl[v]) set(-v);
+  }
+  uint32_t acc = 0;
+  for (int w = 0; w < UN_MAPW; w++) { out[UN_MAPW + w] = acc; acc += (uint32_t)__builtin_popcount(out[w]); }
+}
+
+extern "C" int sacopt_unpredict_stereo_frames(sacopt_ctx *c, int profile, int nframes, const sacopt_dec_frame *frames,
+                                              const double *coefs) {
+  if (!c) return 1;
+  if (begin_call(c)) return 1;
+  ProfDesc pd;
+  if (!get_prof(profile, &pd)) { c->err = "unknown profile"; return 1; }
+  if (nframes < 0 || (nframes && !frames)) { c->err = "bad arguments"; return 1; }
+  if (!nframes) return 0;
+  double base[3 * SACOPT_MAX_COEFS];
+  sacopt_base_profile(profile, base);
+  size_t need = 1 << 20;
+  for (int f = 0; f < nframes; f++) {
+    const sacopt_dec_frame &d = frames[f];
+    if (d.numsamples < 0 || (d.numsamples && (!d.e0 || !d.e1 || !d.v0 || !d.v1))) { c->err = "bad frame"; return 1; }
+    need += 4 * (((size_t)d.numsamples * 4 + 255) & ~(size_t)255) + 2 * (2 * UN_MAPW * 4 + 256) + sizeof(UnJob) + 1024;
+  }
+  if (arena_reserve(c, need)) return 1;
+  HIPCK(c, hipEventRecord(c->ev0, c->st));
+  std::vector<UnJob> jobs(nframes);
+  std::vector<std::vector<uint32_t>> tabs;  // pageable staging for the async uploads: alive until the stream is synchronised
+  tabs.reserve(2 * (size_t)nframes);
+  for (int f = 0; f < nframes; f++) {
+    const sacopt_dec_frame &d = frames[f];
+    UnJob &j = jobs[f];
+    memset(&j, 0, sizeof(j));
+    const int n = d.numsamples;
+    const int32_t *src[2] = {d.e0, d.e1};
+    int32_t *dst[2] = {d.v0, d.v1};
+    const uint8_t *used[2] = {d.used0, d.used1};
+    for (int k = 0; k < 2; k++) {
+      if (n && to_dev(c, src[k], n, &j.e[k])) return 1;
+      j.v[k] = (n && is_device_ptr(dst[k])) ? dst[k] : arena_alloc<int32_t>(c, n ? n : 1);
+      if (!j.v[k]) { c->err = "device arena exhausted"; return 1; }
+      if (used[k] && profile != SACOPT_PROFILE_FAST) {  // StereoFast::Unpredict never unmaps (profile.cpp:34-43)
+        tabs.emplace_back(2 * UN_MAPW);
+        build_unmap_table(used[k], tabs.back().data());
+        uint32_t *dm = arena_alloc<uint32_t>(c, 2 * UN_MAPW);
+        if (!dm) { c->err = "device arena exhausted"; return 1; }
+        HIPCK(c, hipMemcpyAsync(dm, tabs.back().data(), 2 * UN_MAPW * 4, hipMemcpyHostToDevice, c->st));
+        j.map[k] = dm;
+      }
+      j.minval[k] = d.minval[k];
+      j.maxval[k] = d.maxval[k];
+    }
+    j.n = n;
+    for (int i = 0; i < pd.ncoef; i++) j.coef[i] = coefs ? coefs[(size_t)f * pd.ncoef + i] : base[3 * i + 2];
+  }
+  UnJob *dj;
+  if (upload(c, jobs, &dj)) return 1;
+  hipEvent_t a, b;
+  HIPCK(c, hipEventCreate(&a));
+  HIPCK(c, hipEventCreate(&b));
+  HIPCK(c, hipEventRecord(a, c->st));
+  if (sacopt_launch_unpredict(profile, dj, nframes, c->d_tab, c->bits, c->st)) { c->err = "k_unpredict launch failed"; return 1; }
+  HIPCK(c, hipEventRecord(b, c->st));
+  c->lms_ev.push_back({a, b});
+  for (int f = 0; f < nframes; f++) {
+    const size_t bytes = (size_t)frames[f].numsamples * 4;
+    c->lms_units += frames[f].numsamples;
+    if (bytes && jobs[f].v[0] != frames[f].v0 && copy_out(c, frames[f].v0, jobs[f].v[0], bytes)) return 1;
+    if (bytes && jobs[f].v[1] != frames[f].v1 && copy_out(c, frames[f].v1, jobs[f].v[1], bytes)) return 1;
+  }
+  return end_timing(c);
+}
+
 // ------------------------------------------------------------------------------------------ cost on caller residuals
 extern "C" int sacopt_cost_golomb(sacopt_ctx *c, const int32_t *buf, int n, double *state_inout, double *cost) {
   if (!c) return 1;
@@ -1274,15 +1365,6 @@ extern "C" int sacopt_cost_meanrms(sacopt_ctx *c, const int32_t *buf, int n, dou
 }
 
 // ------------------------------------------------------------------------------------------ stage-level entry points
-template <class T>
-static int to_dev(sacopt_ctx *c, const T *src, size_t count, const T **out) {
-  if (is_device_ptr(src)) { *out = src; return 0; }
-  T *p = arena_alloc<T>(c, count);
-  if (!p) { c->err = "device arena exhausted"; return 1; }
-  HIPCK(c, hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, c->st));
-  *out = p;
-  return 0;
-}
 
 extern "C" int sacopt_lms_pair(sacopt_ctx *c, int S, int D, double mu1, double mu2, const double *x0, const double *x1, int n,
                                double *p0, double *p1) {

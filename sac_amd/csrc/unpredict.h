@@ -1,0 +1,405 @@
+// Decoder-side cascade: FrameCoder::UnpredictStereoFrame (src/codec.cpp:216-235) with
+// Stereo{Fast,Normal,High}::Unpredict + Update (src/profile.cpp:34-43, 89-111, 161-186) and Remap::Unmap
+// (src/coder/map.cpp:154-168). Included by kernels.hip (uses its device helpers).
+//
+// Unlike the encoder, nothing here is feed-forward between stages: the sample v(t) is only known once
+// EVERY stage has predicted, and every stage's next input depends on v(t). So one workgroup decodes one
+// frame with all stages in lockstep, two channel phases per sample (channel 1 predicts from v0(t)):
+//   [A] products of all LMS stages of the channel            (all threads)          | barrier
+//   [B] exact serial sums, side by side on different waves:  (1280,640): spec_exact_sum on waves 0-3,
+//       (256,128): one MFMA chain on wave 4, (32,16)+(8,4): wave 5, LPC3 all-orders + BlendErr predict
+//       (or LPC2) on wave 6                                                          | barrier
+//   [C] wave 7: RLS predict, round, clamp (high), Unmap, v = e + p, CalcError -> next stage inputs | barrier
+// then [D] Update of everything for both channels (all threads), and every k-th sample the Cholesky
+// factorisation + solve (waves 0/1 = channel 0/1). Every scalar is produced by the reference's operation
+// sequence (same helpers as the encoder kernels), so v is bit-identical to the reference decoder's.
+#define UN_NT 1024
+#define UN_IO 256  // residuals / samples staged through LDS, this many per channel at a time
+
+// position of the k-th (1-based) set bit of a 32-bit word that has at least k
+__device__ __forceinline__ int kth_set_bit(uint32_t x, int k) {
+  int pos = 0;
+#pragma unroll
+  for (int s = 16; s; s >>= 1) {
+    const int c = __popc(x & ((1u << s) - 1u));
+    if (k > c) { k -= c; x >>= s; pos += s; }
+  }
+  return pos;
+}
+// Remap::Unmap(pred, merr) (map.cpp:154-168) for a whole wave (arguments and result uniform). mp: LDS, UN_MAPW bitmap
+// words over the values -32768..32768 (bit v+32768; value 0 always set, map.cpp:138) then UN_MAPW counts of set bits
+// in the words before each word (entry 2049 = total). The reference walks err = 1, 2, ... until `merr` used values
+// have been passed: that is a select of the (rank + merr)-th set bit. A stream that asks for more used values than
+// exist makes the reference loop forever; here it returns +-(4*32768 + 1), as the oracle does.
+__device__ __forceinline__ int unmap_wave(const uint32_t *mp, int pred, int merr, int lane) {
+  if (merr == 0) return 0;
+  const uint32_t *bw = mp, *rk = mp + UN_MAPW;
+  const int sgn = merr < 0 ? -1 : 1, need = merr < 0 ? -merr : merr;
+  const int total = (int)rk[2049];
+  const long long ip = (long long)pred + 32768;  // position of pred
+  auto rank_le = [&](long long x) -> int {      // set bits at positions <= x
+    if (x < 0) return 0;
+    if (x > 65536) return total;
+    const int w = (int)(x >> 5), b = (int)(x & 31);
+    return (int)rk[w] + __popc(bw[w] & (0xffffffffu >> (31 - b)));
+  };
+  int kglob, w0;
+  if (sgn > 0) { kglob = rank_le(ip) + need; w0 = ip + 1 < 0 ? 0 : (ip + 1 > 65536 ? 2048 : (int)((ip + 1) >> 5)); }
+  else { kglob = rank_le(ip - 1) - need + 1; w0 = ip - 1 < 0 ? 0 : (ip - 1 > 65536 ? 2048 : (int)((ip - 1) >> 5)); }
+  if (kglob < 1 || kglob > total) return sgn * (4 * 32768 + 1);
+  // word holding the kglob-th set bit: probe 64 words from w0 in the walking direction, else bisect the counts
+  int w = w0 + sgn * lane;
+  const bool in = w >= 0 && w <= 2048;
+  const bool hit = in && (int)rk[w] < kglob && kglob <= (int)rk[w + 1];
+  const unsigned long long m = __ballot(hit);
+  if (m) w = w0 + sgn * (int)__builtin_ctzll(m);
+  else {
+    int lo = 0, hi = 2048;  // invariant: rk[lo] < kglob <= rk[hi + 1]
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if ((int)rk[mid + 1] >= kglob) hi = mid; else lo = mid + 1;
+    }
+    w = lo;
+  }
+  w = __builtin_amdgcn_readfirstlane(w);
+  const long long x = 32ll * w + kth_set_bit(bw[w], kglob - (int)rk[w]);
+  long long d = sgn > 0 ? x - ip : ip - x;  // the oracle stops walking after 4*32768 + 1 steps
+  if (d > 4 * 32768 + 1) d = 4 * 32768 + 1;
+  return (int)(sgn * d);
+}
+
+template <int TYPE>  // 0 fast, 1 normal, 2 high
+__global__ __launch_bounds__(UN_NT) void k_unpredict(const UnJob *__restrict__ jobs, const uint16_t *__restrict__ gtab, int bits) {
+  constexpr bool BIG = TYPE == 2, LMS = TYPE >= 1;
+  constexpr int NS = BIG ? 4 : 3;  // LMS stages (TYPE >= 1): [ (1280,640) ] (256,128) (32,16) (8,4)
+  constexpr int KS = TYPE == 0 ? 32 : 8;
+  constexpr int SEG = L1_SEG, SEGP = L1_SEGP, NSEG = 15, SB = 1280, MB = 2047;
+  constexpr int kM = BIG ? 1 : 0, kS = kM + 1, kT = kM + 2;  // stage numbers of the three smaller LMS stages
+  __shared__ double ringB[2][BIG ? 2048 : 1];  // stage inputs val[c][k+1](t) at [t & mask]
+  __shared__ double ringM[2][512], ringS[2][64], ringT[2][16];
+  __shared__ double prodsB[BIG ? 16 * SEGP : 1];
+  __shared__ double prodsM[384], prodsS[48], prodsT[16];  // (the MFMA chain prefetches a few operands past prodsM)
+  __shared__ int sJ[16][16];
+  __shared__ double sA[16], sX1;
+  __shared__ uint16_t tab[LMS ? RSQ_LDS_MAX : 1];
+  __shared__ double vh[2][64];  // decoded samples as doubles, [t & 63]
+  __shared__ double snapL[2][LPC_SNAP], solL[2][LPC_TRI];
+  __shared__ double pst[8];      // p[0..NS] of the channel being decoded (profile.cpp:128-132)
+  __shared__ double errL[2][4];  // val[c][k+1] - p[k+1]: LMSADA2::Update's err (nlms.h:116) per stage
+  __shared__ uint32_t mapL[2][2 * UN_MAPW];
+  __shared__ int32_t ebuf[2][UN_IO], vbuf[2][UN_IO];
+
+  const UnJob &job = jobs[blockIdx.x];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = job.n;
+  bits &= 0xff;
+  const bool mapped0 = LMS && job.map[0], mapped1 = LMS && job.map[1];
+  if (LMS) for (int i = tid; i < (2 << bits); i += UN_NT) tab[i] = gtab[i];
+  if (BIG) for (int i = tid; i < 2 * 2048; i += UN_NT) (&ringB[0][0])[i] = 0.;
+  if (BIG) for (int i = tid; i < 16 * SEGP; i += UN_NT) prodsB[i] = 0.;
+  for (int i = tid; i < 2 * 512; i += UN_NT) (&ringM[0][0])[i] = 0.;
+  if (tid < 128) (&ringS[0][0])[tid] = 0.;
+  if (tid < 32) (&ringT[0][0])[tid] = 0.;
+  if (tid < 16) prodsT[tid] = 0.;
+  if (tid < 128) (&vh[0][0])[tid] = 0.;
+  for (int i = tid; i < 2 * LPC_TRI; i += UN_NT) (&solL[0][0])[i] = 0.;
+  if (mapped0) for (int i = tid; i < 2 * UN_MAPW; i += UN_NT) mapL[0][i] = job.map[0][i];
+  if (mapped1) for (int i = tid; i < 2 * UN_MAPW; i += UN_NT) mapL[1][i] = job.map[1][i];
+
+  // ---- per-thread state
+  // (1280,640): wave s owns segment s (taps 128 s + 64 r + lane), for both channels
+  double wB[2][2], gB[2][2], hB[2][2], muB[2];
+  int offB[2];  // own: lag 1+i; other: j = i - 1280 (lag j + lagx of the channel)
+  bool ownB[2];
+  const bool vB = BIG && wave < NSEG;
+#pragma unroll
+  for (int r = 0; r < 2; r++) {
+    const int i = SEG * wave + 64 * r + lane;
+    ownB[r] = i < SB;
+    offB[r] = ownB[r] ? 1 + i : i - SB;
+    muB[r] = ownB[r] ? job.coef[1] : job.coef[2];
+    wB[0][r] = wB[1][r] = gB[0][r] = gB[1][r] = hB[0][r] = hB[1][r] = 0.;
+  }
+  // (256,128): threads 0..383; (32,16): wave 15 lanes 0..47; (8,4): wave 15 lanes 48..59
+  const bool vM = LMS && tid < 384, vS = LMS && wave == 15 && lane < 48, vT = LMS && wave == 15 && lane >= 48 && lane < 60;
+  const int iT = lane - 48;
+  const bool ownM = tid < 256, ownS = lane < 32, ownT = iT < 8;
+  const int offM = ownM ? 1 + tid : tid - 256, offS = ownS ? 1 + lane : lane - 32, offT = ownT ? 1 + iT : iT - 8;
+  const int cM = BIG ? 3 : 1;  // coefficient numbers (codec.cpp:8-30)
+  const double muM = ownM ? job.coef[cM] : job.coef[cM + 1], muS = job.coef[cM + 2], muT = job.coef[cM + 3];
+  double wM[2] = {0., 0.}, gM[2] = {0., 0.}, hM[2] = {0., 0.};
+  double wS[2] = {0., 0.}, gS[2] = {0., 0.}, hS[2] = {0., 0.};  // (32,16) or (8,4) tap of wave 15
+  // AutoCov element (cov.h:13-51): threads 0..647, channel tid / 324
+  const int cch = tid / LPC_SNAP, ce = tid - cch * LPC_SNAP;
+  const bool vC = tid < 2 * LPC_SNAP, isc = ce < LPC_TRI;
+  int cj = 0, ci = 0;
+  if (isc) { while ((cj + 1) * (cj + 2) / 2 <= ce) cj++; ci = ce - cj * (cj + 1) / 2; }
+  else ci = ce - LPC_TRI;
+  double cv = (vC && isc && ci == cj) ? 1.0 : 0.0;  // cov.h:17
+  const double alpha = job.coef[0];
+  // hist[i] of LPC channel ch at time t (cov.h:44-47 as indices): i < 16 own v(t-1-i), else other v(t - lagb - (i-16))
+  auto lpc_h = [&](int ch, int i, int t) -> double {
+    const int idx = (i < LPC_S) ? (t - 1 - i) : (t - (ch == 0 ? 1 : 0) - (i - LPC_S));
+    return vh[(i < LPC_S) ? ch : 1 - ch][idx & 63];
+  };
+  // BlendErr (blend.h:7-53) of both channels: wave 6, lane o = order o, lane 24 = the blended prediction's error
+  double ssumv[2] = {0., 0.}, bserr[2] = {0., 0.}, bwt[2] = {0., 0.}, pmv[2] = {0., 0.};
+  // RLS mixer (rls.cpp:61-108): wave 7, unit u = lane >> 4 = channel (units 2, 3 idle), lane (i, j) owns P[i][j]
+  const int ri = (lane >> 2) & 3, rj = lane & 3, ru = lane >> 4, base16 = lane & ~15;
+  const bool inm = ri < NS && rj < NS;
+  double rP = (inm && ri == rj) ? 1. : 0., rw[NS], rh[2][NS], rp[2] = {0., 0.}, rx1[2] = {0., 0.};
+#pragma unroll
+  for (int k = 0; k < NS; k++) rw[k] = rh[0][k] = rh[1][k] = 0.;
+  const double ralpha = LMS ? job.coef[BIG ? 7 : 5] : 1.;
+  const double ria = 1. / ralpha;
+  const int mk = lane >> 4;  // MFMA operand lane: term 4s + mk at step s
+  const int32_t mnv[2] = {job.minval[0], job.minval[1]}, mxv[2] = {job.maxval[0], job.maxval[1]};
+  long long rounds = 0;
+  __syncthreads();
+
+  for (int t = 0; t < n; t++) {
+    if ((t & (UN_IO - 1)) == 0) {
+      if (t > 0) {
+        __syncthreads();
+        for (int k = tid; k < 2 * UN_IO; k += UN_NT) (k < UN_IO ? job.v[0] : job.v[1])[t - UN_IO + (k & (UN_IO - 1))] = (&vbuf[0][0])[k];
+      }
+      for (int k = tid; k < 2 * UN_IO; k += UN_NT) {
+        const int tau = t + (k & (UN_IO - 1));
+        (&ebuf[0][0])[k] = tau < n ? (k < UN_IO ? job.e[0] : job.e[1])[tau] : 0;
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+      const int lagx = c == 0 ? 1 : 0;  // channel 0 sees the other channel up to t-1, channel 1 up to t (profile.cpp:128-132)
+      // ---- [A] products w[i]*hist[i] (nlms.h:111)
+      if constexpr (LMS) {
+        if constexpr (BIG) {
+          double part = 0.;
+#pragma unroll
+          for (int r = 0; r < 2; r++) {
+            const double h = ownB[r] ? ringB[c][(t - offB[r]) & MB] : ringB[1 - c][(t - lagx - offB[r]) & MB];
+            hB[c][r] = h;
+            const double pr = wB[c][r] * h;
+            if (vB) prodsB[wave * SEGP + 64 * r + lane] = pr;
+            part += pr;
+          }
+          // approximate segment sum (tree order: a guess only)
+          part = row_prefix16(part);
+          {
+            int lo = __double2loint(part), hi = __double2hiint(part);
+            lo = __builtin_amdgcn_update_dpp(0, lo, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1 and 3
+            hi = __builtin_amdgcn_update_dpp(0, hi, 0x142, 0xA, 0xF, false);
+            part += __hiloint2double(hi, lo);
+            lo = __double2loint(part); hi = __double2hiint(part);
+            lo = __builtin_amdgcn_update_dpp(0, lo, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2 and 3
+            hi = __builtin_amdgcn_update_dpp(0, hi, 0x143, 0xC, 0xF, false);
+            part += __hiloint2double(hi, lo);
+          }
+          if (lane == 63 && vB) sA[wave] = part;
+        }
+        if (vM) {
+          const double h = ownM ? ringM[c][(t - offM) & 511] : ringM[1 - c][(t - lagx - offM) & 511];
+          hM[c] = h;
+          prodsM[tid] = wM[c] * h;
+        }
+        if (vS) {
+          const double h = ownS ? ringS[c][(t - offS) & 63] : ringS[1 - c][(t - lagx - offS) & 63];
+          hS[c] = h;
+          prodsS[lane] = wS[c] * h;
+        }
+        if (vT) {
+          const double h = ownT ? ringT[c][(t - offT) & 15] : ringT[1 - c][(t - lagx - offT) & 15];
+          hS[c] = h;
+          prodsT[iT] = wS[c] * h;
+        }
+        __syncthreads();
+      }
+      // ---- [B] the strict left-to-right sums (nlms.h:110-111, lpc.h:190-199, blend.h:15-17); waves 4..6 do theirs before
+      // they join spec_exact_sum's barrier as bystanders, i.e. while waves 0..3 sum the candidates
+      if (LMS && wave == 4) {
+        const double acc = mfma_chain_lds<6>((uint32_t)(uintptr_t)&prodsM[mk]);
+        if (lane == 0) pst[kM + 1] = acc;
+      }
+      if (LMS && wave == 5) {
+        double a3[12], a4[3], acc3 = 0., acc4 = 0.;
+#pragma unroll
+        for (int u = 0; u < 12; u++) a3[u] = prodsS[4 * u + mk];
+#pragma unroll
+        for (int u = 0; u < 3; u++) a4[u] = prodsT[4 * u + mk];
+#pragma unroll
+        for (int u = 0; u < 12; u++) acc3 = __builtin_amdgcn_mfma_f64_4x4x4f64(a3[u], 1.0, acc3, 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 3; u++) acc4 = __builtin_amdgcn_mfma_f64_4x4x4f64(a4[u], 1.0, acc4, 0, 0, 0);
+        if (lane == 0) { pst[kS + 1] = acc3; pst[kT + 1] = acc4; }
+      }
+      if (wave == 6) {
+        if constexpr (LMS) {  // LPC3::Predict: all-orders sums, then BlendErr::Predict
+          double sum = 0.;
+#pragma unroll
+          for (int i = 0; i < LPC_N; i++) {
+            const double h = lpc_h(c, i, t);
+            if (i <= lane && lane < LPC_N) sum += solL[c][lane * (lane + 1) / 2 + i] * h;
+          }
+          ssumv[c] = sum;
+          const double pr = bwt[c] * sum;
+          double pm = 0.;
+#pragma unroll
+          for (int i = 0; i < LPC_N; i++) pm += bcast(pr, i);
+          pmv[c] = pm;
+          if (lane == 0) pst[0] = pm;
+        } else {  // LPC2::Predict (lpc.h:261-267)
+          double p = 0.;
+#pragma unroll
+          for (int i = 0; i < LPC_N; i++) p += solL[c][i] * lpc_h(c, i, t);
+          if (lane == 0) pst[0] = p;
+        }
+      }
+      if constexpr (BIG) {
+        const double res = spec_exact_sum<NSEG, SEG / 4, SEGP>((uint32_t)(uintptr_t)&prodsB[0], sJ, &sX1, sA, wave < 4 ? wave : -1,
+                                                               wave == 0, 0, rounds);
+        if (wave == 0 && lane == 16 * ((NSEG - 1) & 3) + 4 * ((NSEG - 1) >> 2)) pst[1] = res;
+      }
+      __syncthreads();
+      // ---- [C] mix, round, unmap, reconstruct, CalcError (profile.cpp:134-148, 161-174)
+      if (wave == 7) {
+        const int32_t e_in = ebuf[c][t & (UN_IO - 1)];
+        int32_t v;
+        double val[NS + 1];
+        if constexpr (LMS) {
+          double h[NS];
+          h[0] = pst[1];
+#pragma unroll
+          for (int k = 1; k < NS; k++) h[k] = h[k - 1] + pst[k + 1];  // pv (profile.cpp:134)
+          double p = 0.;
+#pragma unroll
+          for (int k = 0; k < NS; k++) p += h[k] * rw[k];  // RLS::Predict (rls.cpp:67-72), this lane's unit
+          const double pc = bcast(p, 16 * c);
+          int32_t q = cvt_i32_x86(round(pst[0] + pc));
+          if (BIG) q = q < mnv[c] ? mnv[c] : (q > mxv[c] ? mxv[c] : q);  // profile.cpp:163,170
+          int32_t e = e_in;
+          if (c == 0 ? mapped0 : mapped1) e = unmap_wave(mapL[c], q, e, lane);
+          v = (int32_t)((uint32_t)e + (uint32_t)q);  // wraps like the reference build
+          val[0] = (double)v;
+#pragma unroll
+          for (int k = 1; k <= NS; k++) val[k] = val[k - 1] - pst[k - 1];  // CalcError (profile.cpp:141-148)
+#pragma unroll
+          for (int k = 0; k < NS; k++) rh[c][k] = h[k];
+          rp[c] = pc; rx1[c] = val[1];
+          if (lane == 0) {
+            if (BIG) ringB[c][t & MB] = val[1];
+            ringM[c][t & 511] = val[kM + 1];
+            ringS[c][t & 63] = val[kS + 1];
+            ringT[c][t & 15] = val[kT + 1];
+#pragma unroll
+            for (int k = 0; k < NS; k++) errL[c][k] = val[k + 1] - pst[k + 1];
+          }
+        } else {
+          v = cvt_i32_x86((double)e_in + round(pst[0]));  // profile.cpp:37,41
+        }
+        if (lane == 0) { vh[c][t & 63] = (double)v; vbuf[c][t & (UN_IO - 1)] = v; }
+      }
+      __syncthreads();
+    }
+    // ---- [D] Update (profile.cpp:102-111, 176-186)
+    if constexpr (LMS) {
+#pragma unroll
+      for (int c = 0; c < 2; c++) {
+        if (vB) {
+          const double err = errL[c][0];
+#pragma unroll
+          for (int r = 0; r < 2; r++) {
+            const double grad = err * hB[c][r];
+            gB[c][r] = 0.95 * gB[c][r] + (1.0 - 0.95) * (grad * grad);
+            wB[c][r] += (muB[r] * grad * rsq_emul2(gB[c][r] + 0.001, tab, bits));
+          }
+        }
+        if (vM) {
+          const double grad = errL[c][kM] * hM[c];
+          gM[c] = 0.95 * gM[c] + (1.0 - 0.95) * (grad * grad);
+          wM[c] += (muM * grad * rsq_emul2(gM[c] + 0.001, tab, bits));
+        }
+        if (vS || vT) {
+          const double grad = (vS ? errL[c][kS] : errL[c][kT]) * hS[c];
+          gS[c] = 0.95 * gS[c] + (1.0 - 0.95) * (grad * grad);
+          wS[c] += ((vS ? muS : muT) * grad * rsq_emul2(gS[c] + 0.001, tab, bits));
+        }
+      }
+      if (wave == 6) {  // BlendErr::Update((int32_t)val0) (blend.h:30-46)
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+          const double val = vh[c][t & 63];
+          const double e = val - (lane == LPC_N ? pmv[c] : ssumv[c]);
+          bserr[c] = 0.98 * bserr[c] + (1. - 0.98) * (e * e);
+          const double tt = 10000. / (bserr[c] + 0.0001);
+          double wv = tt * tt, wsum = 0;
+#pragma unroll
+          for (int i = 0; i < LPC_N; i++) wsum += bcast(wv, i);
+          if (wsum > 0) wv /= wsum;
+          bwt[c] = wv;
+        }
+      }
+      if (wave == 7) {  // RLS::Update(val[ch][1]) (rls.cpp:80-108), unit = channel
+        double h[NS];
+#pragma unroll
+        for (int k = 0; k < NS; k++) h[k] = ru ? rh[1][k] : rh[0][k];
+        const double p = ru ? rp[1] : rp[0], cx1 = ru ? rx1[1] : rx1[0];
+        double pc[NS];  // column j of P (before the update): P[k][j]
+#pragma unroll
+        for (int k = 0; k < NS; k++) pc[k] = __shfl(rP, base16 + 4 * k + rj);
+        const double pr = rP * pick<NS>(h, rj);  // P[i][j]*hist[j]
+        double vt = 0.;                          // vt1[i] = sum_j P[i][j]*hist[j]
+        vt += quad_bcast<0>(pr);
+        vt += quad_bcast<1>(pr);
+        vt += quad_bcast<2>(pr);
+        if (NS > 3) vt += quad_bcast<3>(pr);
+        double v1[NS];
+#pragma unroll
+        for (int k = 0; k < NS; k++) v1[k] = __shfl(vt, base16 + 4 * k);
+        double inner = 0.;
+#pragma unroll
+        for (int k = 0; k < NS; k++) inner += h[k] * v1[k];
+        const double sc = 1. / (ralpha + inner);
+        double kk[NS];
+#pragma unroll
+        for (int k = 0; k < NS; k++) kk[k] = sc * v1[k];
+        const double ki = pick<NS>(kk, ri);
+        double m2 = 0.;  // m2[i][j] = sum_k (k[i]*hist[k])*P[k][j]
+#pragma unroll
+        for (int k = 0; k < NS; k++) m2 += (ki * h[k]) * pc[k];
+        rP = ria * (rP - m2);
+        const double dv = cx1 - p;
+#pragma unroll
+        for (int k = 0; k < NS; k++) rw[k] = rw[k] + dv * kk[k];
+      }
+    }
+    if (vC) {  // AutoCov::UpdateCov / UpdateB (cov.h:19-43)
+      const double hi = lpc_h(cch, ci, t);
+      const double hj = isc ? lpc_h(cch, cj, t) : vh[cch][t & 63];
+      if (isc) cv = alpha * cv + (hi * hj);
+      else cv = alpha * cv + (hj * hi);
+    }
+    if (((t + 1) % KS) == 0) {  // lpc.h:213-219 / :277-283
+      if (vC) snapL[cch][ce] = cv;
+      __syncthreads();
+      if (wave < 2) chol_wave<TYPE == 0>(snapL[wave], solL[wave], lane);  // "matrix indefinit": the previous solution stays
+      __syncthreads();
+    }
+  }
+  __syncthreads();
+  if (n > 0) {
+    const int tb = (n - 1) & ~(UN_IO - 1);
+    for (int k = tid; k < 2 * UN_IO; k += UN_NT) {
+      const int tau = tb + (k & (UN_IO - 1));
+      if (tau < n) (k < UN_IO ? job.v[0] : job.v[1])[tau] = (&vbuf[0][0])[k];
+    }
+  }
+}
+
+extern "C" int sacopt_launch_unpredict(int type, const UnJob *jobs, int njobs, const uint16_t *tab, int bits, hipStream_t st) {
+  if (njobs <= 0) return 0;
+  if (type == 0) hipLaunchKernelGGL(k_unpredict<0>, dim3(njobs), dim3(UN_NT), 0, st, jobs, tab, bits);
+  else if (type == 1) hipLaunchKernelGGL(k_unpredict<1>, dim3(njobs), dim3(UN_NT), 0, st, jobs, tab, bits);
+  else if (type == 2) hipLaunchKernelGGL(k_unpredict<2>, dim3(njobs), dim3(UN_NT), 0, st, jobs, tab, bits);
+  else return 1;
+  return hipGetLastError() != hipSuccess;
+}

@@ -25,6 +25,11 @@ class Residuals(C.Structure):
                 ("map0", C.c_void_p), ("map1", C.c_void_p), ("maxbpn", C.c_int32 * 4)]
 
 
+class DecFrame(C.Structure):
+    _fields_ = [("e0", C.c_void_p), ("e1", C.c_void_p), ("v0", C.c_void_p), ("v1", C.c_void_p), ("numsamples", C.c_int32),
+                ("used0", C.c_void_p), ("used1", C.c_void_p), ("minval", C.c_int32 * 2), ("maxval", C.c_int32 * 2)]
+
+
 _lib = None
 
 
@@ -48,6 +53,7 @@ def lib():
         L.sacopt_optimize_frames.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                              C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.sacopt_encode_frames.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.sacopt_unpredict_stereo_frames.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.sacopt_cost_golomb.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.sacopt_cost_meanrms.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.sacopt_lms_pair.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p,
@@ -60,7 +66,7 @@ def lib():
 
 
 EXPORTS = ["sacopt_create", "sacopt_destroy", "sacopt_last_error", "sacopt_probe_rsqrt", "sacopt_base_profile",
-           "sacopt_predict_stereo_frames", "sacopt_get_costs", "sacopt_optimize_frames", "sacopt_encode_frames", "sacopt_cost_golomb",
+           "sacopt_predict_stereo_frames", "sacopt_get_costs", "sacopt_optimize_frames", "sacopt_encode_frames", "sacopt_unpredict_stereo_frames", "sacopt_cost_golomb",
            "sacopt_cost_meanrms", "sacopt_lms_pair", "sacopt_lpc3_pair", "sacopt_rls_run", "sacopt_last_timing"]
 
 
@@ -215,6 +221,30 @@ class Context:
         for i in range(nf):
             outs[i]["maxbpn"] = np.array(list(res[i].maxbpn), np.int32)
         return best, outs
+
+    def unpredict(self, profile, frames, coefs=None):
+        """frames: list of dicts e0, e1 (numpy int32) [, used0, used1 (uint8[2*32769] or None), minmax (min0,max0,min1,max1)].
+        Returns list of (v0, v1)."""
+        nf = len(frames)
+        arr = (DecFrame * max(nf, 1))()
+        keep, outs = [], []
+        for i, fr in enumerate(frames):
+            e0 = np.ascontiguousarray(fr["e0"], dtype=np.int32); e1 = np.ascontiguousarray(fr["e1"], dtype=np.int32)
+            v0 = np.zeros(len(e0), np.int32); v1 = np.zeros(len(e0), np.int32)
+            u = [None if fr.get(k) is None else np.ascontiguousarray(fr[k], dtype=np.uint8) for k in ("used0", "used1")]
+            keep += [e0, e1] + u
+            outs.append((v0, v1))
+            arr[i].e0, arr[i].e1, arr[i].v0, arr[i].v1 = e0.ctypes.data, e1.ctypes.data, v0.ctypes.data, v1.ctypes.data
+            arr[i].numsamples = len(e0)
+            arr[i].used0 = None if u[0] is None else u[0].ctypes.data
+            arr[i].used1 = None if u[1] is None else u[1].ctypes.data
+            mm = fr.get("minmax")
+            if mm is None:
+                mm = (-2 ** 31, 2 ** 31 - 1, -2 ** 31, 2 ** 31 - 1)
+            arr[i].minval[0], arr[i].maxval[0], arr[i].minval[1], arr[i].maxval[1] = [int(x) for x in mm]
+        cf = None if coefs is None else np.ascontiguousarray(coefs, dtype=np.float64)
+        self._ck(lib().sacopt_unpredict_stereo_frames(self._h, profile, nf, arr, _p(cf)))
+        return outs
 
     def cost_golomb(self, buf, state=0.0):
         st = np.array([state], np.float64)

@@ -1,0 +1,96 @@
+"""GPU: sacopt_unpredict_stereo_frames (decoder-side cascade) through the C ABI against the golden
+fixtures generated from the reference (tests/golden/golden_unpredict.npz) and the oracle. int32 samples, bit-exact.
+Runs with the FIXTURE's rsqrtss table."""
+import numpy as np
+import pytest
+
+from sac_amd import sacopt
+from sac_amd.synth import stereo_clip, degenerate_clips
+from test_oracle_golden import unpredict_cases
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx(rsqrt_table):
+    c = sacopt.Context(0, *rsqrt_table)
+    yield c
+    c.close()
+
+
+def _frame(e, kw):
+    return dict(e0=e[0], e1=e[1], used0=kw.get("used0"), used1=kw.get("used1"), minmax=kw.get("minmax"))
+
+
+def test_unpredict_golden(ctx, golden_unpredict):
+    # every fixture case of FrameCoder::UnpredictStereoFrame (codec.cpp:216-235): plain, garbage residuals, mapped
+    # channels (Remap::Unmap, map.cpp:154-168), the high profile's clamp (profile.cpp:163,170), custom coefficients
+    for name, prof, e, kw, want in unpredict_cases(golden_unpredict):
+        cf = kw.get("coefs")
+        v = ctx.unpredict(prof, [_frame(e, kw)], coefs=None if cf is None else np.asarray(cf)[None, :])[0]
+        assert np.array_equal(v[0], want[0]) and np.array_equal(v[1], want[1]), name
+
+
+@pytest.mark.parametrize("prof", [0, 1, 2])
+def test_unpredict_batch_ragged(ctx, oracle, prof):
+    # several frames of different lengths in one call (one workgroup each), empty and 1-sample frames included;
+    # encode on the GPU, decode on the GPU, compare with the input and with the oracle's decoder
+    lens = [0, 1, 255, 256, 257, 1031, 3000]
+    clips = [stereo_clip(70 + i, max(n, 1)) for i, n in enumerate(lens)]
+    clips = [(L[:n], R[:n]) for (L, R), n in zip(clips, lens)]
+    enc = ctx.predict(prof, [(L, R) for L, R in clips])
+    dec = ctx.unpredict(prof, [dict(e0=d["e0"], e1=d["e1"]) for d in enc])
+    for (L, R), d, v in zip(clips, enc, dec):
+        o = oracle.unpredict(prof, d["e0"], d["e1"])
+        assert np.array_equal(v[0], o[0]) and np.array_equal(v[1], o[1])
+        assert np.array_equal(v[0], L) and np.array_equal(v[1], R)
+
+
+@pytest.mark.parametrize("prof", [1, 2])
+def test_unpredict_mapped_roundtrip(ctx, oracle, prof):
+    # sparse sample values (every 7th level): the mapped residuals differ from the plain ones; one channel mapped,
+    # then both; the decoder gets the tables of Remap::Analyse
+    L, R = stereo_clip(81, 4000)
+    L = (L // 7) * 7
+    R = (R // 5) * 5
+    enc = ctx.predict(prof, [(L, R)], maps=True)[0]
+    s2u_inv = lambda u: np.where(u & 1, ((u.astype(np.int64) + 1) >> 1), -(u.astype(np.int64) >> 1)).astype(np.int32)  # utils.h:62-66
+    m0, m1 = s2u_inv(enc["m0"]), s2u_inv(enc["m1"])
+    assert not np.array_equal(m0, enc["e0"])
+    u0, u1 = oracle.remap_tables(L), oracle.remap_tables(R)
+    for e, kw in (((m0, enc["e1"]), dict(used0=u0)), ((enc["e0"], m1), dict(used1=u1)), ((m0, m1), dict(used0=u0, used1=u1))):
+        v = ctx.unpredict(prof, [_frame(e, kw)])[0]
+        o = oracle.unpredict(prof, *e, **kw)
+        assert np.array_equal(v[0], o[0]) and np.array_equal(v[1], o[1])
+        assert np.array_equal(v[0], L) and np.array_equal(v[1], R)
+
+
+def test_unpredict_unmap_out_of_table(ctx, oracle):
+    # residuals that ask for more used values than the table holds / predictions far outside +-32768
+    rng = np.random.default_rng(5)
+    n = 600
+    e0 = rng.integers(-40000, 40000, n).astype(np.int32)
+    e1 = rng.integers(-300, 300, n).astype(np.int32)
+    L, R = stereo_clip(82, 2000)
+    u0, u1 = oracle.remap_tables((L // 9) * 9), oracle.remap_tables(R)
+    for prof in (1, 2):
+        kw = dict(used0=u0, used1=u1)
+        v = ctx.unpredict(prof, [_frame((e0, e1), kw)])[0]
+        o = oracle.unpredict(prof, e0, e1, **kw)
+        assert np.array_equal(v[0], o[0]) and np.array_equal(v[1], o[1])
+
+
+def test_unpredict_degenerate(ctx, oracle):
+    for name, (L, R) in degenerate_clips(1500).items():
+        for prof in (0, 1, 2):
+            e = oracle.predict(prof, L, R)
+            v = ctx.unpredict(prof, [dict(e0=e["e0"], e1=e["e1"])])[0]
+            assert np.array_equal(v[0], L) and np.array_equal(v[1], R), (name, prof)
+
+
+def test_unpredict_long_high(ctx, oracle):
+    # crosses several factorisation periods, IO blocks and the (1280,640) history length
+    L, R = stereo_clip(83, 12000)
+    e = ctx.predict(2, [(L, R)])[0]
+    v = ctx.unpredict(2, [dict(e0=e["e0"], e1=e["e1"])])[0]
+    assert np.array_equal(v[0], L) and np.array_equal(v[1], R)
