@@ -68,6 +68,11 @@ __device__ __forceinline__ int unmap_wave(const uint32_t *mp, int pred, int merr
   return (int)(sgn * d);
 }
 
+// Out of line: the factorisation holds a matrix row and a solution row per lane (96 VGPRs). Inlined, the allocator
+// spills the per-sample state of every wave around it; as a call, only waves 0/1 pay, every k-th sample.
+template <bool FAST>
+__device__ __noinline__ void chol_wave_call(const double *snap, double *solo, int lane) { chol_wave<FAST>(snap, solo, lane); }
+
 template <int TYPE>  // 0 fast, 1 normal, 2 high
 __global__ __launch_bounds__(UN_NT) void k_unpredict(const UnJob *__restrict__ jobs, const uint16_t *__restrict__ gtab, int bits) {
   constexpr bool BIG = TYPE == 2, LMS = TYPE >= 1;
@@ -88,6 +93,10 @@ __global__ __launch_bounds__(UN_NT) void k_unpredict(const UnJob *__restrict__ j
   __shared__ double errL[2][4];  // val[c][k+1] - p[k+1]: LMSADA2::Update's err (nlms.h:116) per stage
   __shared__ uint32_t mapL[2][2 * UN_MAPW];
   __shared__ int32_t ebuf[2][UN_IO], vbuf[2][UN_IO];
+  // state only one wave touches lives in LDS, [slot][lane], not in registers (a 1024-thread workgroup has 128 per lane):
+  // BlendErr of wave 6 (slots c: ssum, 2+c: serr, 4+c: w, 6+c: pm), RLS of wave 7 (0: P[i][j], 1..4: w, 5+4c+k: hist,
+  // 13+c: p, 15+c: val[c][1])
+  __shared__ double blS[8][64], rlS[17][64];
 
   const UnJob &job = jobs[blockIdx.x];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = job.n;
@@ -107,7 +116,7 @@ __global__ __launch_bounds__(UN_NT) void k_unpredict(const UnJob *__restrict__ j
 
   // ---- per-thread state
   // (1280,640): wave s owns segment s (taps 128 s + 64 r + lane), for both channels
-  double wB[2][2], gB[2][2], hB[2][2], muB[2];
+  double wB[2][2], gB[2][2], muB[2];  // (the history values are read again from the rings in [D]: registers are short)
   int offB[2];  // own: lag 1+i; other: j = i - 1280 (lag j + lagx of the channel)
   bool ownB[2];
   const bool vB = BIG && wave < NSEG;
@@ -117,7 +126,7 @@ __global__ __launch_bounds__(UN_NT) void k_unpredict(const UnJob *__restrict__ j
     ownB[r] = i < SB;
     offB[r] = ownB[r] ? 1 + i : i - SB;
     muB[r] = ownB[r] ? job.coef[1] : job.coef[2];
-    wB[0][r] = wB[1][r] = gB[0][r] = gB[1][r] = hB[0][r] = hB[1][r] = 0.;
+    wB[0][r] = wB[1][r] = gB[0][r] = gB[1][r] = 0.;
   }
   // (256,128): threads 0..383; (32,16): wave 15 lanes 0..47; (8,4): wave 15 lanes 48..59
   const bool vM = LMS && tid < 384, vS = LMS && wave == 15 && lane < 48, vT = LMS && wave == 15 && lane >= 48 && lane < 60;
@@ -126,8 +135,8 @@ __global__ __launch_bounds__(UN_NT) void k_unpredict(const UnJob *__restrict__ j
   const int offM = ownM ? 1 + tid : tid - 256, offS = ownS ? 1 + lane : lane - 32, offT = ownT ? 1 + iT : iT - 8;
   const int cM = BIG ? 3 : 1;  // coefficient numbers (codec.cpp:8-30)
   const double muM = ownM ? job.coef[cM] : job.coef[cM + 1], muS = job.coef[cM + 2], muT = job.coef[cM + 3];
-  double wM[2] = {0., 0.}, gM[2] = {0., 0.}, hM[2] = {0., 0.};
-  double wS[2] = {0., 0.}, gS[2] = {0., 0.}, hS[2] = {0., 0.};  // (32,16) or (8,4) tap of wave 15
+  double wM[2] = {0., 0.}, gM[2] = {0., 0.};
+  double wS[2] = {0., 0.}, gS[2] = {0., 0.};  // (32,16) or (8,4) tap of wave 15
   // AutoCov element (cov.h:13-51): threads 0..647, channel tid / 324
   const int cch = tid / LPC_SNAP, ce = tid - cch * LPC_SNAP;
   const bool vC = tid < 2 * LPC_SNAP, isc = ce < LPC_TRI;
@@ -142,13 +151,13 @@ __global__ __launch_bounds__(UN_NT) void k_unpredict(const UnJob *__restrict__ j
     return vh[(i < LPC_S) ? ch : 1 - ch][idx & 63];
   };
   // BlendErr (blend.h:7-53) of both channels: wave 6, lane o = order o, lane 24 = the blended prediction's error
-  double ssumv[2] = {0., 0.}, bserr[2] = {0., 0.}, bwt[2] = {0., 0.}, pmv[2] = {0., 0.};
+  for (int i = tid; i < 8 * 64; i += UN_NT) (&blS[0][0])[i] = 0.;
+  for (int i = tid; i < 17 * 64; i += UN_NT) (&rlS[0][0])[i] = 0.;
   // RLS mixer (rls.cpp:61-108): wave 7, unit u = lane >> 4 = channel (units 2, 3 idle), lane (i, j) owns P[i][j]
   const int ri = (lane >> 2) & 3, rj = lane & 3, ru = lane >> 4, base16 = lane & ~15;
   const bool inm = ri < NS && rj < NS;
-  double rP = (inm && ri == rj) ? 1. : 0., rw[NS], rh[2][NS], rp[2] = {0., 0.}, rx1[2] = {0., 0.};
-#pragma unroll
-  for (int k = 0; k < NS; k++) rw[k] = rh[0][k] = rh[1][k] = 0.;
+  __syncthreads();
+  if (wave == 7) rlS[0][lane] = (inm && ri == rj) ? 1. : 0.;  // P = I (rls.h)
   const double ralpha = LMS ? job.coef[BIG ? 7 : 5] : 1.;
   const double ria = 1. / ralpha;
   const int mk = lane >> 4;  // MFMA operand lane: term 4s + mk at step s
@@ -178,7 +187,6 @@ __global__ __launch_bounds__(UN_NT) void k_unpredict(const UnJob *__restrict__ j
 #pragma unroll
           for (int r = 0; r < 2; r++) {
             const double h = ownB[r] ? ringB[c][(t - offB[r]) & MB] : ringB[1 - c][(t - lagx - offB[r]) & MB];
-            hB[c][r] = h;
             const double pr = wB[c][r] * h;
             if (vB) prodsB[wave * SEGP + 64 * r + lane] = pr;
             part += pr;
@@ -199,17 +207,14 @@ __global__ __launch_bounds__(UN_NT) void k_unpredict(const UnJob *__restrict__ j
         }
         if (vM) {
           const double h = ownM ? ringM[c][(t - offM) & 511] : ringM[1 - c][(t - lagx - offM) & 511];
-          hM[c] = h;
           prodsM[tid] = wM[c] * h;
         }
         if (vS) {
           const double h = ownS ? ringS[c][(t - offS) & 63] : ringS[1 - c][(t - lagx - offS) & 63];
-          hS[c] = h;
           prodsS[lane] = wS[c] * h;
         }
         if (vT) {
           const double h = ownT ? ringT[c][(t - offT) & 15] : ringT[1 - c][(t - lagx - offT) & 15];
-          hS[c] = h;
           prodsT[iT] = wS[c] * h;
         }
         __syncthreads();
@@ -240,12 +245,12 @@ __global__ __launch_bounds__(UN_NT) void k_unpredict(const UnJob *__restrict__ j
             const double h = lpc_h(c, i, t);
             if (i <= lane && lane < LPC_N) sum += solL[c][lane * (lane + 1) / 2 + i] * h;
           }
-          ssumv[c] = sum;
-          const double pr = bwt[c] * sum;
+          blS[c][lane] = sum;
+          const double pr = blS[4 + c][lane] * sum;
           double pm = 0.;
 #pragma unroll
           for (int i = 0; i < LPC_N; i++) pm += bcast(pr, i);
-          pmv[c] = pm;
+          blS[6 + c][lane] = pm;
           if (lane == 0) pst[0] = pm;
         } else {  // LPC2::Predict (lpc.h:261-267)
           double p = 0.;
@@ -272,7 +277,7 @@ __global__ __launch_bounds__(UN_NT) void k_unpredict(const UnJob *__restrict__ j
           for (int k = 1; k < NS; k++) h[k] = h[k - 1] + pst[k + 1];  // pv (profile.cpp:134)
           double p = 0.;
 #pragma unroll
-          for (int k = 0; k < NS; k++) p += h[k] * rw[k];  // RLS::Predict (rls.cpp:67-72), this lane's unit
+          for (int k = 0; k < NS; k++) p += h[k] * rlS[1 + k][lane];  // RLS::Predict (rls.cpp:67-72), this lane's unit
           const double pc = bcast(p, 16 * c);
           int32_t q = cvt_i32_x86(round(pst[0] + pc));
           if (BIG) q = q < mnv[c] ? mnv[c] : (q > mxv[c] ? mxv[c] : q);  // profile.cpp:163,170
@@ -283,8 +288,8 @@ __global__ __launch_bounds__(UN_NT) void k_unpredict(const UnJob *__restrict__ j
 #pragma unroll
           for (int k = 1; k <= NS; k++) val[k] = val[k - 1] - pst[k - 1];  // CalcError (profile.cpp:141-148)
 #pragma unroll
-          for (int k = 0; k < NS; k++) rh[c][k] = h[k];
-          rp[c] = pc; rx1[c] = val[1];
+          for (int k = 0; k < NS; k++) rlS[5 + 4 * c + k][lane] = h[k];
+          rlS[13 + c][lane] = pc; rlS[15 + c][lane] = val[1];
           if (lane == 0) {
             if (BIG) ringB[c][t & MB] = val[1];
             ringM[c][t & 511] = val[kM + 1];
@@ -304,22 +309,27 @@ __global__ __launch_bounds__(UN_NT) void k_unpredict(const UnJob *__restrict__ j
     if constexpr (LMS) {
 #pragma unroll
       for (int c = 0; c < 2; c++) {
+        const int lagx = c == 0 ? 1 : 0;
         if (vB) {
           const double err = errL[c][0];
 #pragma unroll
           for (int r = 0; r < 2; r++) {
-            const double grad = err * hB[c][r];
+            const double h = ownB[r] ? ringB[c][(t - offB[r]) & MB] : ringB[1 - c][(t - lagx - offB[r]) & MB];
+            const double grad = err * h;
             gB[c][r] = 0.95 * gB[c][r] + (1.0 - 0.95) * (grad * grad);
             wB[c][r] += (muB[r] * grad * rsq_emul2(gB[c][r] + 0.001, tab, bits));
           }
         }
         if (vM) {
-          const double grad = errL[c][kM] * hM[c];
+          const double h = ownM ? ringM[c][(t - offM) & 511] : ringM[1 - c][(t - lagx - offM) & 511];
+          const double grad = errL[c][kM] * h;
           gM[c] = 0.95 * gM[c] + (1.0 - 0.95) * (grad * grad);
           wM[c] += (muM * grad * rsq_emul2(gM[c] + 0.001, tab, bits));
         }
         if (vS || vT) {
-          const double grad = (vS ? errL[c][kS] : errL[c][kT]) * hS[c];
+          const double h = vS ? (ownS ? ringS[c][(t - offS) & 63] : ringS[1 - c][(t - lagx - offS) & 63])
+                              : (ownT ? ringT[c][(t - offT) & 15] : ringT[1 - c][(t - lagx - offT) & 15]);
+          const double grad = (vS ? errL[c][kS] : errL[c][kT]) * h;
           gS[c] = 0.95 * gS[c] + (1.0 - 0.95) * (grad * grad);
           wS[c] += ((vS ? muS : muT) * grad * rsq_emul2(gS[c] + 0.001, tab, bits));
         }
@@ -328,21 +338,23 @@ __global__ __launch_bounds__(UN_NT) void k_unpredict(const UnJob *__restrict__ j
 #pragma unroll
         for (int c = 0; c < 2; c++) {
           const double val = vh[c][t & 63];
-          const double e = val - (lane == LPC_N ? pmv[c] : ssumv[c]);
-          bserr[c] = 0.98 * bserr[c] + (1. - 0.98) * (e * e);
-          const double tt = 10000. / (bserr[c] + 0.0001);
+          const double e = val - (lane == LPC_N ? blS[6 + c][lane] : blS[c][lane]);
+          const double se = 0.98 * blS[2 + c][lane] + (1. - 0.98) * (e * e);
+          blS[2 + c][lane] = se;
+          const double tt = 10000. / (se + 0.0001);
           double wv = tt * tt, wsum = 0;
 #pragma unroll
           for (int i = 0; i < LPC_N; i++) wsum += bcast(wv, i);
           if (wsum > 0) wv /= wsum;
-          bwt[c] = wv;
+          blS[4 + c][lane] = wv;
         }
       }
       if (wave == 7) {  // RLS::Update(val[ch][1]) (rls.cpp:80-108), unit = channel
         double h[NS];
 #pragma unroll
-        for (int k = 0; k < NS; k++) h[k] = ru ? rh[1][k] : rh[0][k];
-        const double p = ru ? rp[1] : rp[0], cx1 = ru ? rx1[1] : rx1[0];
+        for (int k = 0; k < NS; k++) h[k] = rlS[5 + 4 * (ru & 1) + k][lane];
+        const double p = rlS[13 + (ru & 1)][lane], cx1 = rlS[15 + (ru & 1)][lane];
+        double rP = rlS[0][lane];
         double pc[NS];  // column j of P (before the update): P[k][j]
 #pragma unroll
         for (int k = 0; k < NS; k++) pc[k] = __shfl(rP, base16 + 4 * k + rj);
@@ -366,10 +378,10 @@ __global__ __launch_bounds__(UN_NT) void k_unpredict(const UnJob *__restrict__ j
         double m2 = 0.;  // m2[i][j] = sum_k (k[i]*hist[k])*P[k][j]
 #pragma unroll
         for (int k = 0; k < NS; k++) m2 += (ki * h[k]) * pc[k];
-        rP = ria * (rP - m2);
+        rlS[0][lane] = ria * (rP - m2);
         const double dv = cx1 - p;
 #pragma unroll
-        for (int k = 0; k < NS; k++) rw[k] = rw[k] + dv * kk[k];
+        for (int k = 0; k < NS; k++) rlS[1 + k][lane] = rlS[1 + k][lane] + dv * kk[k];
       }
     }
     if (vC) {  // AutoCov::UpdateCov / UpdateB (cov.h:19-43)
@@ -381,7 +393,7 @@ __global__ __launch_bounds__(UN_NT) void k_unpredict(const UnJob *__restrict__ j
     if (((t + 1) % KS) == 0) {  // lpc.h:213-219 / :277-283
       if (vC) snapL[cch][ce] = cv;
       __syncthreads();
-      if (wave < 2) chol_wave<TYPE == 0>(snapL[wave], solL[wave], lane);  // "matrix indefinit": the previous solution stays
+      if (wave < 2) chol_wave_call<TYPE == 0>(snapL[wave], solL[wave], lane);  // "matrix indefinit": the previous solution stays
       __syncthreads();
     }
   }

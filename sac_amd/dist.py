@@ -41,3 +41,134 @@ def gather_frame_rows(local_rows: np.ndarray, nframes: int, world: int, rank: in
         l, h = frame_shard(nframes, world, r)
         out[l:h] = parts[r].cpu().numpy()[:h - l]
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# One frame's candidate population across GPUs (BASELINE config 5)
+# ---------------------------------------------------------------------------------------------
+class SacoptEvaluator:
+    """What optimize_split needs from a device: residuals of candidate parameter sets over a window
+    (FrameCoder::PredictStereoFrame, src/codec.cpp:154-214) and CostGolomb::Calc with its carried running
+    mean (src/codec.cpp:315-339), both through the C ABI of libsacopt."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def window_residuals(self, profile, frames, start, n, coefs):
+        """frames: list of (s0, s1); coefs[f]: [k, ncoef] -> out[f][c] = (e0, e1) of candidate c of frame f."""
+        k = len(coefs[0]) if coefs else 0
+        if k == 0:
+            return [[] for _ in frames]
+        flat = [fr for fr in frames for _ in range(k)]
+        res = self.ctx.predict(profile, flat, frm=[s for s in start for _ in range(k)], n=[m for m in n for _ in range(k)],
+                               coefs=np.concatenate([np.asarray(c, np.float64).reshape(k, -1) for c in coefs]))
+        return [[(res[f * k + c]["e0"], res[f * k + c]["e1"]) for c in range(k)] for f in range(len(frames))]
+
+    def cost_golomb(self, buf, state):
+        return self.ctx.cost_golomb(buf, state)
+
+
+def _gather_rows(local, nrows, world, rank, group):
+    return gather_frame_rows(np.asarray(local, np.float64).reshape(-1, np.asarray(local).shape[-1]), nrows, world, rank, group)
+
+
+def optimize_split(ev, profile, frames, prof, ncoef_loop, world=1, rank=0, group=None, stats=None):
+    """FrameCoder::Optimize (src/codec.cpp:354-408) with every round's candidate grid split over `world` ranks.
+
+    Each rank evaluates a contiguous slice of the round's candidates (for all `frames`, same profile table `prof` =
+    ncoef x {vmin, vmax, vdef}); costs are all-gathered and every rank takes the same argmin with the reference's strict
+    `<` in call order (lowest index wins ties, codec.cpp:399). The one CostGolomb instance of an Optimize call carries its
+    running mean from candidate to candidate (codec.cpp:364), i.e. across ranks. It forgets its start (0.98^n), so each
+    rank first publishes the mean its LAST candidate ends with when started from 0 (a guess), every rank starts its slice
+    from its predecessor's guess and carries the true mean inside the slice, and the guess is checked against the mean
+    the predecessor actually ended with: all equal => exact by induction from rank 0, whose start is the true carried
+    state. Any mismatch (short windows) => the slices are re-costed rank after rank from the true state (broadcasts).
+    stats (optional dict) counts rounds whose guesses verified / that needed the chain.
+    Returns (best[nframes, ncoef], traces: per frame rows {coef (-1 = baseline call), x, cost} in call order)."""
+    import torch
+    import torch.distributed as dist
+    prof = np.asarray(prof, np.float64).reshape(-1, 3)
+    ncoef, nf = len(prof), len(frames)
+    if ncoef_loop > ncoef:
+        raise ValueError("ncoef_loop exceeds the profile's coefficient count")
+    cur = np.tile(prof[:, 2], (nf, 1))            # profile.coefs[i].vdef per frame
+    wn = [len(fr[0]) // 8 for fr in frames]       # codec.cpp:356-359
+    st = [(len(fr[0]) - w) // 2 for fr, w in zip(frames, wn)]
+    state = np.zeros(nf)                          # CostGolomb::mean_err, one instance per Optimize call
+    best_cost = np.zeros(nf)
+    traces = [[] for _ in range(nf)]
+    dev = None
+    if world > 1:
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    for i in range(ncoef_loop):
+        xs = []
+        x, xinc = prof[i, 0], (prof[i, 1] - prof[i, 0]) / 10.
+        while x <= prof[i, 1]:                    # codec.cpp:392-403
+            xs.append(x)
+            x += xinc
+        cands = [(-1, prof[0, 2])] * (i == 0) + [(i, x) for x in xs]  # the baseline call (codec.cpp:386) rides with round 0
+        nc = len(cands)
+        lo, hi = frame_shard(nc, world, rank)
+        mine = cands[lo:hi]
+        coefs = []
+        for f in range(nf):
+            cf = np.tile(cur[f], (len(mine), 1))
+            for c, (ci, x) in enumerate(mine):
+                cf[c, max(ci, 0)] = x
+            coefs.append(cf)
+        res = ev.window_residuals(profile, frames, st, wn, coefs)
+
+        def cost_slice(start_state):
+            costs, s = np.zeros((len(mine), nf)), np.array(start_state, np.float64)
+            for f in range(nf):
+                for c in range(len(mine)):
+                    c1, s[f] = ev.cost_golomb(res[f][c][0], s[f])   # GetCost, codec.cpp:349-351
+                    c2, s[f] = ev.cost_golomb(res[f][c][1], s[f])
+                    costs[c, f] = (c1 + c2) / 2.
+            return costs, s
+
+        if world == 1:
+            costs, state = cost_slice(state)
+        else:
+            # pass 1: the mean my last candidate ends with, started from 0
+            guess = np.zeros((1, nf))
+            if mine:
+                for f in range(nf):
+                    _, g = ev.cost_golomb(res[f][-1][0], 0.0)
+                    _, guess[0, f] = ev.cost_golomb(res[f][-1][1], g)
+            guesses = _gather_rows(guess, world, world, rank, group)
+            # pass 2: my slice from my predecessor's guess (rank 0: the true carried state)
+            my_costs, my_end = cost_slice(state if rank == 0 else guesses[rank - 1])
+            ok = 1.0 if (not mine or my_end.tobytes() == guesses[rank].tobytes()) else 0.0
+            tail = _gather_rows(np.concatenate([my_end, [ok]])[None, :], world, world, rank, group)
+            active = min(world, nc)               # ranks with a non-empty slice (empty ones are trailing)
+            if all(tail[r, nf] == 1.0 for r in range(active - 1)):   # the last slice's guess feeds nobody
+                costs = _gather_rows(my_costs if mine else np.zeros((0, nf)), nc, world, rank, group)
+                state = tail[active - 1, :nf].copy()
+                if stats is not None:
+                    stats["verified"] = stats.get("verified", 0) + 1
+            else:
+                if stats is not None:
+                    stats["chained"] = stats.get("chained", 0) + 1
+                costs = np.zeros((nc, nf))
+                for r in range(active):
+                    l, h = frame_shard(nc, world, r)
+                    buf = torch.zeros((h - l + 1, nf), dtype=torch.float64)
+                    if rank == r:
+                        c_r, e_r = cost_slice(state)
+                        buf = torch.from_numpy(np.concatenate([c_r, e_r[None, :]]))
+                    buf = buf.to(dev)
+                    dist.broadcast(buf, src=r if group is None else dist.get_global_rank(group, r), group=group)
+                    b = buf.cpu().numpy()
+                    costs[l:h] = b[:-1]
+                    state = b[-1].copy()
+        for f in range(nf):
+            best_x = cur[f, i]
+            for c, (ci, x) in enumerate(cands):
+                traces[f].append((float(ci), x, costs[c, f]))
+                if ci < 0:
+                    best_cost[f] = costs[c, f]
+                elif costs[c, f] < best_cost[f]:  # codec.cpp:399
+                    best_x, best_cost[f] = x, costs[c, f]
+            cur[f, i] = best_x                    # codec.cpp:406
+    return cur, [np.array(t, np.float64).reshape(-1, 3) for t in traces]

@@ -66,3 +66,85 @@ def test_frame_shard_properties():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
             sizes = [h - l for l, h in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+# ---------------------------------------------------------------------------------------------
+# One frame's candidate population split over two ranks (BASELINE config 5): the schedule of
+# sac_amd.dist.optimize_split with the oracle standing in for the device (no GPU in this tier) must reproduce the
+# oracle's own FrameCoder::Optimize row for row: costs (CostGolomb state carried across ranks), argmin, selected values.
+# ---------------------------------------------------------------------------------------------
+class _OracleEvaluator:
+    def __init__(self):
+        from oracle_lib import Oracle
+        d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rsqrt_table.npz"))
+        self.o = Oracle()
+        self.o.set_rsqrt_table(d["tab"].astype(np.float32), int(d["bits"]))
+
+    def window_residuals(self, profile, frames, start, n, coefs):
+        out = []
+        for (s0, s1), a, m, cf in zip(frames, start, n, coefs):
+            rs = [self.o.predict(profile, s0, s1, frm=a, n=m, coefs=c) for c in cf]
+            out.append([(r["e0"], r["e1"]) for r in rs])
+        return out
+
+    def cost_golomb(self, buf, state):
+        return self.o.cost_golomb(buf, state)
+
+
+def _split_worker(rank, world, port, profile, lens, ncoef_loop, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sac_amd.dist import optimize_split
+    from sac_amd.synth import stereo_clip
+    ev = _OracleEvaluator()
+    frames = [stereo_clip(40 + k, n) for k, n in enumerate(lens)]
+    stats = {}
+    best, traces = optimize_split(ev, profile, frames, ev.o.base_profile(profile), ncoef_loop, world, rank, stats=stats)
+    q.put((rank, best, traces, stats))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("profile,lens,ncoef_loop", [
+    (2, [4000], 8),           # 500-sample window: the running mean has not forgotten its start -> guesses fail, rank chain
+    (1, [34000, 33000], 6),   # >= 4125-sample windows: guesses verify, costs gathered in one collective; two frames
+    (0, [2000], 1),           # one coefficient: round 0 = baseline + 11 candidates
+])
+def test_two_rank_candidate_split(oracle, profile, lens, ncoef_loop):
+    from sac_amd.synth import stereo_clip
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_split_worker, args=(r, world, port, profile, lens, ncoef_loop, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for k, n in enumerate(lens):
+        L, R = stereo_clip(40 + k, n)
+        want_best, want_trace = oracle.optimize(profile, L, R, ncoef_loop=ncoef_loop)
+        for rank, best, traces, stats in got:
+            assert traces[k].tobytes() == want_trace.tobytes(), (rank, k)
+            assert best[k].tobytes() == want_best[:len(best[k])].tobytes(), (rank, k)
+    for rank, best, traces, stats in got:  # both mechanisms are exercised: short windows chain, long ones verify
+        assert stats.get("chained", 0) + stats.get("verified", 0) == ncoef_loop
+        if max(lens) <= 4000:
+            assert stats.get("chained", 0) > 0
+        else:
+            assert stats.get("verified", 0) == ncoef_loop
+
+
+def test_candidate_split_world1_matches_oracle(oracle):
+    from sac_amd.dist import optimize_split
+    from sac_amd.synth import stereo_clip
+    L, R = stereo_clip(44, 3000)
+    ev = _OracleEvaluator()
+    best, traces = optimize_split(ev, 2, [(L, R)], oracle.base_profile(2), 8)
+    want_best, want_trace = oracle.optimize(2, L, R)
+    assert traces[0].tobytes() == want_trace.tobytes() and best[0].tobytes() == want_best.tobytes()
