@@ -6,6 +6,9 @@
 //   PredictStereoFrame(profile,0,1,from,n) src/codec.cpp:154-214
 //   GetCost(profile,coef,testval,start,n)  src/codec.cpp:341-352  (CostGolomb state carried, :364)
 //   Optimize(profile)                      src/codec.cpp:354-408
+//   Unpredict() / UnpredictStereoFrame(profile,0,1,n)  src/codec.cpp:463-478, :216-235 (decoder side; UnpredictBatch
+//                                          for a batch of frames). framestats[ch].enc_mapped / mymap / minval / maxval
+//                                          (src/codec.h:49) appear as enc_mapped[ch] / used[ch] / minval[ch] / maxval[ch].
 // Buffers are the reference's public members (samples / error / s2u_error / s2u_error_map, src/codec.h:29-31);
 // maxbpn / maxbpn_map stand for framestats[ch].maxbpn{,_map} (src/codec.h:49, src/codec.cpp:207-211).
 // PredictBatch is the batched form a throughput-minded Codec::EncodeFile would call.
@@ -117,11 +120,65 @@ class FrameCoder {
     for (size_t i = 0; i < best.size(); i++) profile.coefs[i].vdef = best[i];
   }
 
+  // Remap::Analyse (src/coder/map.cpp:111-130) as the byte tables the MapEncoder codes (usedl[0..32768], usedh[0..32768])
+  static std::vector<uint8_t> AnalyseUsed(const int32_t *src, int n) {
+    std::vector<uint8_t> u(2 * 32769, 0);
+    for (int i = 0; i < n; i++) {
+      const int64_t v = src[i];
+      if (v > 0 && v <= 32768) u[32769 + v] = 1;
+      else if (v < 0 && -v <= 32768) u[-v] = 1;
+    }
+    return u;
+  }
+
+  // FrameCoder::Unpredict (codec.cpp:463-478): error[ch] (mapped where enc_mapped[ch]) -> samples[ch], base profile
+  void Unpredict() {
+    FrameCoder *self = this;
+    UnpredictBatch(&self, 1);
+  }
+  void UnpredictStereoFrame(const SacProfile &profile, int ch0, int ch1, int n) {
+    if (ch0 != 0 || ch1 != 1) throw std::invalid_argument("channel order");
+    sacopt_dec_frame d = dec_frame(n);
+    std::vector<double> c(profile.coefs.size());
+    for (size_t i = 0; i < c.size(); i++) c[i] = profile.coefs[i].vdef;
+    check(sacopt_unpredict_stereo_frames(ctx_, profile.type, 1, &d, c.data()));
+  }
+  // with_optprofile: decode with each frame's optprofile (streams that carry optimised parameters)
+  static void UnpredictBatch(FrameCoder *const *fc, int nframes, bool with_optprofile = false) {
+    if (nframes <= 0) return;
+    FrameCoder &f0 = *fc[0];
+    const int ncoef = (int)f0.baseprofile.coefs.size();
+    std::vector<sacopt_dec_frame> d(nframes);
+    std::vector<double> c((size_t)nframes * ncoef);
+    for (int b = 0; b < nframes; b++) {
+      FrameCoder &f = *fc[b];
+      if (f.baseprofile.type != f0.baseprofile.type) throw std::invalid_argument("mixed profiles in one batch");
+      d[b] = f.dec_frame(f.numsamples);
+      const SacProfile &p = with_optprofile ? f.optprofile : f.baseprofile;
+      for (int i = 0; i < ncoef; i++) c[(size_t)b * ncoef + i] = p.coefs[i].vdef;
+    }
+    f0.check(sacopt_unpredict_stereo_frames(f0.ctx_, f0.baseprofile.type, nframes, d.data(), c.data()));
+  }
+
   std::vector<std::vector<int32_t>> samples, error, s2u_error, s2u_error_map;
   int maxbpn[2], maxbpn_map[2];
+  bool enc_mapped[2] = {false, false};
+  std::vector<uint8_t> used[2];
+  int32_t minval[2] = {INT32_MIN, INT32_MIN}, maxval[2] = {INT32_MAX, INT32_MAX};
   SacProfile baseprofile, optprofile;
 
  private:
+  sacopt_dec_frame dec_frame(int n) {
+    sacopt_dec_frame d = {};
+    d.e0 = error[0].data(); d.e1 = error[1].data(); d.v0 = samples[0].data(); d.v1 = samples[1].data(); d.numsamples = n;
+    d.used0 = enc_mapped[0] ? used[0].data() : nullptr;
+    d.used1 = enc_mapped[1] ? used[1].data() : nullptr;
+    for (int k = 0; k < 2; k++) {
+      if (enc_mapped[k] && used[k].size() != 2 * 32769) throw std::invalid_argument("enc_mapped without Remap tables");
+      d.minval[k] = minval[k]; d.maxval[k] = maxval[k];
+    }
+    return d;
+  }
   void check(int rc) { if (rc) throw std::runtime_error(std::string("sacopt: ") + sacopt_last_error(ctx_)); }
   sacopt_ctx *ctx_;
   int numchannels, framesize, numsamples = 0;

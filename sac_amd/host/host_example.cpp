@@ -2,6 +2,7 @@
 // reference's FrameCoder on this path) and prints, per frame, the selected parameters and checksums of the
 // residual arrays. tests/test_gpu_parity.py::test_cpp_host_framecoder compares the output with the ctypes path.
 //   usage: host_example <profile> <nframes> <numsamples> <optimize 0|1>
+#include <algorithm>
 #include <cinttypes>
 #include <cstdio>
 #include <cstdlib>
@@ -44,6 +45,25 @@ int main(int argc, char **argv) {
       ptr.push_back(fc[b].get());
     }
     sacopt::FrameCoder::PredictBatch(ptr.data(), nframes, optimize != 0);
+    // decoder round trip (FrameCoder::Unpredict, codec.cpp:463-478): channel 0 from its plain residuals, channel 1 as a
+    // mapped channel (U2S of s2u_error_map, utils.h:62-66, with the Remap tables of the frame); samples are overwritten
+    std::vector<std::vector<int32_t>> keep0(nframes), keep1(nframes), keepe1(nframes);
+    for (int b = 0; b < nframes; b++) {
+      sacopt::FrameCoder &f = *fc[b];
+      keep0[b] = f.samples[0]; keep1[b] = f.samples[1]; keepe1[b] = f.error[1];
+      f.enc_mapped[1] = true;
+      f.used[1] = sacopt::FrameCoder::AnalyseUsed(f.samples[1].data(), n);
+      for (int i = 0; i < n; i++) { const int32_t u = f.s2u_error_map[1][i]; f.error[1][i] = (u & 1) ? ((u + 1) >> 1) : -(u >> 1); }
+      std::fill(f.samples[0].begin(), f.samples[0].end(), 0);
+      std::fill(f.samples[1].begin(), f.samples[1].end(), 0);
+    }
+    sacopt::FrameCoder::UnpredictBatch(ptr.data(), nframes);
+    std::vector<int> dec_ok(nframes);
+    for (int b = 0; b < nframes; b++) {
+      sacopt::FrameCoder &f = *fc[b];
+      dec_ok[b] = f.samples[0] == keep0[b] && f.samples[1] == keep1[b];
+      f.samples[0] = keep0[b]; f.samples[1] = keep1[b]; f.error[1] = keepe1[b];
+    }
     for (int b = 0; b < nframes; b++) {
       sacopt::FrameCoder &f = *fc[b];
       printf("frame %d in %016" PRIx64 " %016" PRIx64 " err %016" PRIx64 " %016" PRIx64 " s2u %016" PRIx64 " %016" PRIx64
@@ -52,7 +72,7 @@ int main(int argc, char **argv) {
              fnv(f.s2u_error[0].data(), n), fnv(f.s2u_error[1].data(), n), fnv(f.s2u_error_map[0].data(), n),
              fnv(f.s2u_error_map[1].data(), n), f.maxbpn[0], f.maxbpn[1], f.maxbpn_map[0], f.maxbpn_map[1]);
       for (auto &c : f.optprofile.coefs) printf(" %.17g", c.vdef);
-      printf("\n");
+      printf(" decode %s\n", dec_ok[b] ? "ok" : "MISMATCH");
     }
   } catch (const std::exception &e) {
     fprintf(stderr, "%s\n", e.what());

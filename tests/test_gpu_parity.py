@@ -286,6 +286,7 @@ def test_cpp_host_framecoder():
         assert [int(x, 16) for x in ln[12:14]] == [_fnv(o["m0"]), _fnv(o["m1"])]
         assert [int(x) for x in ln[15:19]] == list(o["maxbpn"])
         assert same_bits(np.array([float(x) for x in ln[20:28]]), best[b])
+        assert ln[28:30] == ["decode", "ok"]  # FrameCoder::Unpredict of the C++ mirror (one channel mapped) restores the samples
 
 
 # ---------------------------------------------------------------- BASELINE sizes (176400-sample frames)

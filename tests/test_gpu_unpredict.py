@@ -94,3 +94,18 @@ def test_unpredict_long_high(ctx, oracle):
     e = ctx.predict(2, [(L, R)])[0]
     v = ctx.unpredict(2, [dict(e0=e["e0"], e1=e["e1"])])[0]
     assert np.array_equal(v[0], L) and np.array_equal(v[1], R)
+
+
+def test_optimised_parameters_round_trip(ctx):
+    # a stream that carries the optimiser's per-frame parameters -- encode each frame with the values
+    # Optimize selected (different per frame), decode with the same values: samples restored; decoding with the base
+    # profile instead does NOT restore them (the parameters really are in the loop)
+    frames = [stereo_clip(90, 9000), stereo_clip(91, 7000)]
+    best, _, _ = ctx.optimize(2, frames)
+    enc = ctx.predict(2, frames, coefs=best)
+    dec = ctx.unpredict(2, [dict(e0=d["e0"], e1=d["e1"]) for d in enc], coefs=best)
+    for (L, R), v in zip(frames, dec):
+        assert np.array_equal(v[0], L) and np.array_equal(v[1], R)
+    if not np.array_equal(best[0], sacopt.base_profile(2)[:, 2]):
+        wrong = ctx.unpredict(2, [dict(e0=enc[0]["e0"], e1=enc[0]["e1"])])[0]
+        assert not np.array_equal(wrong[0], frames[0][0])
