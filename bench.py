@@ -55,6 +55,32 @@ def cpu_baseline(seconds_budget=20.0):
             "sample": f"Optimize (84 candidates x {n // 8}-sample window) + full PredictStereoFrame of one {n}-sample high-profile frame, {dt:.1f} s on one core"}
 
 
+def decode_extra(ctx, torch, nfr, dL, dR, e0, e1):
+    """Not the headline: the decoder-side cascade (sacopt_unpredict_stereo_frames) on the residuals the timed
+    steps left in HBM -- one call for the clip, checked against the input samples -- and the reference's
+    UnpredictStereoFrame on one host core on a bounded sample beside it."""
+    from sac_amd import sacopt
+    v0 = torch.empty_like(dL); v1 = torch.empty_like(dL)
+    fr = [dict(e0=e0.data_ptr() + 4 * f * FRAME, e1=e1.data_ptr() + 4 * f * FRAME, v0=v0.data_ptr() + 4 * f * FRAME,
+               v1=v1.data_ptr() + 4 * f * FRAME, n=FRAME) for f in range(nfr)]
+    ctx.unpredict(sacopt.PROFILE_HIGH, fr)
+    t = ctx.last_timing()
+    out = {"workload": f"UnpredictStereoFrame of the same {nfr} frames (high profile), one workgroup per frame",
+           "ms": t["total_ms"], "kernel_ms": t["lms_ms"], "value": nfr * FRAME / (t["total_ms"] * 1e-3), "unit": "samples/s",
+           "round_trip_ok": bool(torch.equal(v0, dL) and torch.equal(v1, dR))}
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    n = 65536
+    r0 = e0[:n].cpu().numpy(); r1 = e1[:n].cpu().numpy()
+    lib = oracle_lib.Ref() if oracle_lib.have_ref() else oracle_lib.Oracle()
+    t0 = time.perf_counter()
+    lib.unpredict(2, r0, r1)
+    dt = time.perf_counter() - t0
+    out["cpu_baseline"] = {"value": n / dt, "unit": "samples/s", "cores": 1, "kind": "reference" if oracle_lib.have_ref() else "port",
+                           "sample": f"UnpredictStereoFrame of one {n}-sample high-profile frame, {dt:.1f} s on one core"}
+    return out
+
+
 def pmc_traffic():
     """HBM bytes per launch of the dominant kernel from the committed PMC passes of this same command
     (profiles/*_pmc_hbm.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); None if not collected."""
@@ -80,6 +106,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frames", type=int, default=NFRAMES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-decode", action="store_true", help="skip the (untimed) decoder-side extra")
     args = ap.parse_args()
 
     import torch
@@ -163,6 +190,8 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()
+        if not args.no_decode and world == 1:
+            line["decode"] = decode_extra(ctx, torch, nfr, dL, dR, e0, e1)   # after the timed region, not part of `value`
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -97,9 +97,12 @@ __global__ __launch_bounds__(UN_NT) void k_unpredict(const UnJob *__restrict__ j
   // BlendErr of wave 6 (slots c: ssum, 2+c: serr, 4+c: w, 6+c: pm), RLS of wave 7 (0: P[i][j], 1..4: w, 5+4c+k: hist,
   // 13+c: p, 15+c: val[c][1])
   __shared__ double blS[8][64], rlS[17][64];
+  // weights and gradient energies of the three smaller LMS stages ([w ch0, w ch1, eg ch0, eg ch1][tap]); only the
+  // (1280,640) taps stay in registers
+  __shared__ double lmM[4][LMS ? 384 : 1], lmS[4][64];
 
   const UnJob &job = jobs[blockIdx.x];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = job.n;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), n = job.n;  // wave: an SGPR, roles branch on it
   bits &= 0xff;
   const bool mapped0 = LMS && job.map[0], mapped1 = LMS && job.map[1];
   if (LMS) for (int i = tid; i < (2 << bits); i += UN_NT) tab[i] = gtab[i];
@@ -116,27 +119,26 @@ __global__ __launch_bounds__(UN_NT) void k_unpredict(const UnJob *__restrict__ j
 
   // ---- per-thread state
   // (1280,640): wave s owns segment s (taps 128 s + 64 r + lane), for both channels
-  double wB[2][2], gB[2][2], muB[2];  // (the history values are read again from the rings in [D]: registers are short)
+  double wB[2][2], gB[2][2];  // (the history values are read again from the rings in [D]: registers are short)
   int offB[2];  // own: lag 1+i; other: j = i - 1280 (lag j + lagx of the channel)
-  bool ownB[2];
   const bool vB = BIG && wave < NSEG;
+  const bool ownB = wave < SB / SEG;  // segments 0..9 hold the channel's own history, 10..14 the other channel's
+  const double muB = ownB ? job.coef[1] : job.coef[2];
 #pragma unroll
   for (int r = 0; r < 2; r++) {
     const int i = SEG * wave + 64 * r + lane;
-    ownB[r] = i < SB;
-    offB[r] = ownB[r] ? 1 + i : i - SB;
-    muB[r] = ownB[r] ? job.coef[1] : job.coef[2];
+    offB[r] = ownB ? 1 + i : i - SB;
     wB[0][r] = wB[1][r] = gB[0][r] = gB[1][r] = 0.;
   }
   // (256,128): threads 0..383; (32,16): wave 15 lanes 0..47; (8,4): wave 15 lanes 48..59
   const bool vM = LMS && tid < 384, vS = LMS && wave == 15 && lane < 48, vT = LMS && wave == 15 && lane >= 48 && lane < 60;
   const int iT = lane - 48;
-  const bool ownM = tid < 256, ownS = lane < 32, ownT = iT < 8;
+  const bool ownM = wave < 4, ownS = lane < 32, ownT = iT < 8;
   const int offM = ownM ? 1 + tid : tid - 256, offS = ownS ? 1 + lane : lane - 32, offT = ownT ? 1 + iT : iT - 8;
   const int cM = BIG ? 3 : 1;  // coefficient numbers (codec.cpp:8-30)
   const double muM = ownM ? job.coef[cM] : job.coef[cM + 1], muS = job.coef[cM + 2], muT = job.coef[cM + 3];
-  double wM[2] = {0., 0.}, gM[2] = {0., 0.};
-  double wS[2] = {0., 0.}, gS[2] = {0., 0.};  // (32,16) or (8,4) tap of wave 15
+  if (LMS) for (int i = tid; i < 4 * 384; i += UN_NT) (&lmM[0][0])[i] = 0.;
+  if (tid < 4 * 64) (&lmS[0][0])[tid] = 0.;  // (32,16) or (8,4) tap of wave 15
   // AutoCov element (cov.h:13-51): threads 0..647, channel tid / 324
   const int cch = tid / LPC_SNAP, ce = tid - cch * LPC_SNAP;
   const bool vC = tid < 2 * LPC_SNAP, isc = ce < LPC_TRI;
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(UN_NT) void k_unpredict(const UnJob *__restrict__ j
           double part = 0.;
 #pragma unroll
           for (int r = 0; r < 2; r++) {
-            const double h = ownB[r] ? ringB[c][(t - offB[r]) & MB] : ringB[1 - c][(t - lagx - offB[r]) & MB];
+            const double h = ownB ? ringB[c][(t - offB[r]) & MB] : ringB[1 - c][(t - lagx - offB[r]) & MB];
             const double pr = wB[c][r] * h;
             if (vB) prodsB[wave * SEGP + 64 * r + lane] = pr;
             part += pr;
@@ -207,20 +209,26 @@ __global__ __launch_bounds__(UN_NT) void k_unpredict(const UnJob *__restrict__ j
         }
         if (vM) {
           const double h = ownM ? ringM[c][(t - offM) & 511] : ringM[1 - c][(t - lagx - offM) & 511];
-          prodsM[tid] = wM[c] * h;
+          prodsM[tid] = lmM[c][tid] * h;
         }
         if (vS) {
           const double h = ownS ? ringS[c][(t - offS) & 63] : ringS[1 - c][(t - lagx - offS) & 63];
-          prodsS[lane] = wS[c] * h;
+          prodsS[lane] = lmS[c][lane] * h;
         }
         if (vT) {
           const double h = ownT ? ringT[c][(t - offT) & 15] : ringT[1 - c][(t - lagx - offT) & 15];
-          prodsT[iT] = wS[c] * h;
+          prodsT[iT] = lmS[c][lane] * h;
         }
         __syncthreads();
       }
-      // ---- [B] the strict left-to-right sums (nlms.h:110-111, lpc.h:190-199, blend.h:15-17); waves 4..6 do theirs before
-      // they join spec_exact_sum's barrier as bystanders, i.e. while waves 0..3 sum the candidates
+      // ---- [B] the strict left-to-right sums (nlms.h:110-111, lpc.h:190-199, blend.h:15-17). Waves 4..6 pass through
+      // spec_exact_sum's barrier as bystanders first and sum while wave 0 walks and verifies (the (256,128) chain is as
+      // long as walk + verification; in front of the barrier it would delay the walk)
+      if constexpr (BIG) {
+        const double res = spec_exact_sum<NSEG, SEG / 4, SEGP>((uint32_t)(uintptr_t)&prodsB[0], sJ, &sX1, sA, wave < 4 ? wave : -1,
+                                                               wave == 0, 0, rounds);
+        if (wave == 0 && lane == 16 * ((NSEG - 1) & 3) + 4 * ((NSEG - 1) >> 2)) pst[1] = res;
+      }
       if (LMS && wave == 4) {
         const double acc = mfma_chain_lds<6>((uint32_t)(uintptr_t)&prodsM[mk]);
         if (lane == 0) pst[kM + 1] = acc;
@@ -258,11 +266,6 @@ __global__ __launch_bounds__(UN_NT) void k_unpredict(const UnJob *__restrict__ j
           for (int i = 0; i < LPC_N; i++) p += solL[c][i] * lpc_h(c, i, t);
           if (lane == 0) pst[0] = p;
         }
-      }
-      if constexpr (BIG) {
-        const double res = spec_exact_sum<NSEG, SEG / 4, SEGP>((uint32_t)(uintptr_t)&prodsB[0], sJ, &sX1, sA, wave < 4 ? wave : -1,
-                                                               wave == 0, 0, rounds);
-        if (wave == 0 && lane == 16 * ((NSEG - 1) & 3) + 4 * ((NSEG - 1) >> 2)) pst[1] = res;
       }
       __syncthreads();
       // ---- [C] mix, round, unmap, reconstruct, CalcError (profile.cpp:134-148, 161-174)
@@ -314,29 +317,31 @@ __global__ __launch_bounds__(UN_NT) void k_unpredict(const UnJob *__restrict__ j
           const double err = errL[c][0];
 #pragma unroll
           for (int r = 0; r < 2; r++) {
-            const double h = ownB[r] ? ringB[c][(t - offB[r]) & MB] : ringB[1 - c][(t - lagx - offB[r]) & MB];
+            const double h = ownB ? ringB[c][(t - offB[r]) & MB] : ringB[1 - c][(t - lagx - offB[r]) & MB];
             const double grad = err * h;
             gB[c][r] = 0.95 * gB[c][r] + (1.0 - 0.95) * (grad * grad);
-            wB[c][r] += (muB[r] * grad * rsq_emul2(gB[c][r] + 0.001, tab, bits));
+            wB[c][r] += (muB * grad * rsq_emul2(gB[c][r] + 0.001, tab, bits));
           }
         }
         if (vM) {
           const double h = ownM ? ringM[c][(t - offM) & 511] : ringM[1 - c][(t - lagx - offM) & 511];
           const double grad = errL[c][kM] * h;
-          gM[c] = 0.95 * gM[c] + (1.0 - 0.95) * (grad * grad);
-          wM[c] += (muM * grad * rsq_emul2(gM[c] + 0.001, tab, bits));
+          const double g = 0.95 * lmM[2 + c][tid] + (1.0 - 0.95) * (grad * grad);
+          lmM[2 + c][tid] = g;
+          lmM[c][tid] = lmM[c][tid] + (muM * grad * rsq_emul2(g + 0.001, tab, bits));
         }
         if (vS || vT) {
           const double h = vS ? (ownS ? ringS[c][(t - offS) & 63] : ringS[1 - c][(t - lagx - offS) & 63])
                               : (ownT ? ringT[c][(t - offT) & 15] : ringT[1 - c][(t - lagx - offT) & 15]);
           const double grad = (vS ? errL[c][kS] : errL[c][kT]) * h;
-          gS[c] = 0.95 * gS[c] + (1.0 - 0.95) * (grad * grad);
-          wS[c] += ((vS ? muS : muT) * grad * rsq_emul2(gS[c] + 0.001, tab, bits));
+          const double g = 0.95 * lmS[2 + c][lane] + (1.0 - 0.95) * (grad * grad);
+          lmS[2 + c][lane] = g;
+          lmS[c][lane] = lmS[c][lane] + ((vS ? muS : muT) * grad * rsq_emul2(g + 0.001, tab, bits));
         }
       }
-      if (wave == 6) {  // BlendErr::Update((int32_t)val0) (blend.h:30-46)
-#pragma unroll
-        for (int c = 0; c < 2; c++) {
+      if (wave == 6 || wave == 8) {  // BlendErr::Update((int32_t)val0) (blend.h:30-46): channel 0 on wave 6, channel 1 on wave 8
+        const int c = wave == 6 ? 0 : 1;
+        {
           const double val = vh[c][t & 63];
           const double e = val - (lane == LPC_N ? blS[6 + c][lane] : blS[c][lane]);
           const double se = 0.98 * blS[2 + c][lane] + (1. - 0.98) * (e * e);

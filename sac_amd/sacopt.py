@@ -224,18 +224,27 @@ class Context:
 
     def unpredict(self, profile, frames, coefs=None):
         """frames: list of dicts e0, e1 (numpy int32) [, used0, used1 (uint8[2*32769] or None), minmax (min0,max0,min1,max1)].
-        Returns list of (v0, v1)."""
+        Returns list of (v0, v1). Device form: e0, e1, v0, v1 raw device pointers (int) and n; the samples stay on the
+        device and the list holds (v0, v1) pointers."""
         nf = len(frames)
         arr = (DecFrame * max(nf, 1))()
         keep, outs = [], []
         for i, fr in enumerate(frames):
-            e0 = np.ascontiguousarray(fr["e0"], dtype=np.int32); e1 = np.ascontiguousarray(fr["e1"], dtype=np.int32)
-            v0 = np.zeros(len(e0), np.int32); v1 = np.zeros(len(e0), np.int32)
+            if isinstance(fr["e0"], (int, np.integer)):
+                n = int(fr["n"])
+                e0p, e1p, v0, v1 = int(fr["e0"]), int(fr["e1"]), int(fr["v0"]), int(fr["v1"])
+                v0p, v1p = v0, v1
+            else:
+                e0 = np.ascontiguousarray(fr["e0"], dtype=np.int32); e1 = np.ascontiguousarray(fr["e1"], dtype=np.int32)
+                n = len(e0)
+                v0 = np.zeros(n, np.int32); v1 = np.zeros(n, np.int32)
+                keep += [e0, e1]
+                e0p, e1p, v0p, v1p = e0.ctypes.data, e1.ctypes.data, v0.ctypes.data, v1.ctypes.data
             u = [None if fr.get(k) is None else np.ascontiguousarray(fr[k], dtype=np.uint8) for k in ("used0", "used1")]
-            keep += [e0, e1] + u
+            keep += u
             outs.append((v0, v1))
-            arr[i].e0, arr[i].e1, arr[i].v0, arr[i].v1 = e0.ctypes.data, e1.ctypes.data, v0.ctypes.data, v1.ctypes.data
-            arr[i].numsamples = len(e0)
+            arr[i].e0, arr[i].e1, arr[i].v0, arr[i].v1 = e0p, e1p, v0p, v1p
+            arr[i].numsamples = n
             arr[i].used0 = None if u[0] is None else u[0].ctypes.data
             arr[i].used1 = None if u[1] is None else u[1].ctypes.data
             mm = fr.get("minmax")
