@@ -166,6 +166,12 @@ __global__ __launch_bounds__(UN_NT) void k_unpredict(const UnJob *__restrict__ j
   const int32_t mnv[2] = {job.minval[0], job.minval[1]}, mxv[2] = {job.maxval[0], job.maxval[1]};
   long long rounds = 0;
   __syncthreads();
+#ifdef UN_PROF  // phase clocks of wave 0 (a participant of every barrier), written over the first samples of channel 0
+  long long pfA = 0, pfB = 0, pfC = 0, pfD = 0, pfK = 0, pfT = clock64();
+#define UN_TICK(acc) { const long long now_ = clock64(); acc += now_ - pfT; pfT = now_; }
+#else
+#define UN_TICK(acc)
+#endif
 
   for (int t = 0; t < n; t++) {
     if ((t & (UN_IO - 1)) == 0) {
@@ -221,6 +227,7 @@ __global__ __launch_bounds__(UN_NT) void k_unpredict(const UnJob *__restrict__ j
         }
         __syncthreads();
       }
+      UN_TICK(pfA)
       // ---- [B] the strict left-to-right sums (nlms.h:110-111, lpc.h:190-199, blend.h:15-17). Waves 4..6 pass through
       // spec_exact_sum's barrier as bystanders first and sum while wave 0 walks and verifies (the (256,128) chain is as
       // long as walk + verification; in front of the barrier it would delay the walk)
@@ -268,6 +275,7 @@ __global__ __launch_bounds__(UN_NT) void k_unpredict(const UnJob *__restrict__ j
         }
       }
       __syncthreads();
+      UN_TICK(pfB)
       // ---- [C] mix, round, unmap, reconstruct, CalcError (profile.cpp:134-148, 161-174)
       if (wave == 7) {
         const int32_t e_in = ebuf[c][t & (UN_IO - 1)];
@@ -307,6 +315,7 @@ __global__ __launch_bounds__(UN_NT) void k_unpredict(const UnJob *__restrict__ j
         if (lane == 0) { vh[c][t & 63] = (double)v; vbuf[c][t & (UN_IO - 1)] = v; }
       }
       __syncthreads();
+      UN_TICK(pfC)
     }
     // ---- [D] Update (profile.cpp:102-111, 176-186)
     if constexpr (LMS) {
@@ -395,14 +404,21 @@ __global__ __launch_bounds__(UN_NT) void k_unpredict(const UnJob *__restrict__ j
       if (isc) cv = alpha * cv + (hi * hj);
       else cv = alpha * cv + (hj * hi);
     }
+    UN_TICK(pfD)
     if (((t + 1) % KS) == 0) {  // lpc.h:213-219 / :277-283
       if (vC) snapL[cch][ce] = cv;
       __syncthreads();
       if (wave < 2) chol_wave_call<TYPE == 0>(snapL[wave], solL[wave], lane);  // "matrix indefinit": the previous solution stays
       __syncthreads();
+      UN_TICK(pfK)
     }
   }
   __syncthreads();
+#ifdef UN_PROF
+  if (tid == 0 && n >= 256) { vbuf[0][0] = (int32_t)(pfA >> 10); vbuf[0][1] = (int32_t)(pfB >> 10); vbuf[0][2] = (int32_t)(pfC >> 10);
+    vbuf[0][3] = (int32_t)(pfD >> 10); vbuf[0][4] = (int32_t)(pfK >> 10); }
+  __syncthreads();
+#endif
   if (n > 0) {
     const int tb = (n - 1) & ~(UN_IO - 1);
     for (int k = tid; k < 2 * UN_IO; k += UN_NT) {

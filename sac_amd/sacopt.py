@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsacopt.so")
+LIB_PATH = os.environ.get("SACOPT_LIB") or os.path.join(_HERE, "libsacopt.so")  # SACOPT_LIB: instrumented builds of tools/ only
 
 PROFILE_FAST, PROFILE_NORMAL, PROFILE_HIGH = 0, 1, 2
 NCOEF = {0: 1, 1: 6, 2: 8}
