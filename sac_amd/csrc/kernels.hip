@@ -181,11 +181,10 @@ __device__ __forceinline__ int ulp_shift(int v, int ea, int eb) {  // offset in 
 // ------------------------------------------------------------------------------------------
 template <int NSEG, int STEPS, int SEGP>
 __device__ __forceinline__ double spec_exact_sum(uint32_t prods_addr, int (*sJ)[16], double *sX1, const double *sA, int group,
-                                                 bool walker, int dbg, long long &rounds) {
+                                                 bool walker, int dbg, long long &rounds, const int lane) {
   constexpr int NB = NSEG - 1;  // last boundary = input of the last segment
   static_assert(STEPS == 32, "one pass = 32 MFMA steps");
   auto pass = [](uint32_t ad, double c0) { return mfma_pass32(ad, c0); };
-  const int lane = threadIdx.x & 63;
   const int jA = lane & 15, kA = lane >> 4;                      // A-operand lane: chain jA, term 4s+kA at step s
   const int jD = 4 * ((lane >> 2) & 3) + (lane >> 4);             // chain held by this D-layout lane
   int walk_its = 0;
@@ -415,7 +414,7 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
       // and each channel's four candidate waves sit on different SIMDs
       const int sc = wave & 1, grp = wave < 8 ? (wave >> 1) : -1;
       long long rounds_ = 0;
-      const double res = spec_exact_sum<NSEG, SEG / 4, SEGP>((uint32_t)(uintptr_t)&prods[sc][0], sJ[sc], &sX1[sc], sA[sc], grp, grp == 0, dbg, rounds_);
+      const double res = spec_exact_sum<NSEG, SEG / 4, SEGP>((uint32_t)(uintptr_t)&prods[sc][0], sJ[sc], &sX1[sc], sA[sc], grp, grp == 0, dbg, rounds_, lane);
       if (grp == 0 && lane == 16 * ((NSEG - 1) & 3) + 4 * ((NSEG - 1) >> 2)) {
         predv[sc] = res;
         pbuf[sc][t & (CH - 1)] = res;
@@ -601,7 +600,7 @@ __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs
     if (hl == HW - 1 && valid[0]) sA[seg] = part;
     __syncthreads();
     // ---- pred = 0.; for i: pred += w[i]*hist[i]  -- strict order (spec_exact_sum: waves 0..3 sum candidates, wave 0 verifies)
-    const double res = spec_exact_sum<NSEG, SEG / 4, SEGP>((uint32_t)(uintptr_t)&prods[0], sJ, &sX1, sA, wave < 4 ? wave : -1, wave == 0, dbg, rounds);
+    const double res = spec_exact_sum<NSEG, SEG / 4, SEGP>((uint32_t)(uintptr_t)&prods[0], sJ, &sX1, sA, wave < 4 ? wave : -1, wave == 0, dbg, rounds, lane);
     if (wave == 0 && lane == 16 * ((NSEG - 1) & 3) + 4 * ((NSEG - 1) >> 2)) {
       predv = res;
       pbuf[t & (CH - 1)] = res;

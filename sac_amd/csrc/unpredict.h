@@ -7,7 +7,7 @@
 // frame with all stages in lockstep, two channel phases per sample (channel 1 predicts from v0(t)):
 //   [A] products of all LMS stages of the channel            (all threads)          | barrier
 //   [B] exact serial sums, side by side on different waves:  (1280,640): spec_exact_sum on waves 0-3,
-//       (256,128): one MFMA chain on wave 4, (32,16)+(8,4): wave 5, LPC3 all-orders + BlendErr predict
+//       (256,128): one MFMA chain on wave 5, (32,16)+(8,4): wave 7, LPC3 all-orders + BlendErr predict
 //       (or LPC2) on wave 6                                                          | barrier
 //   [C] wave 7: RLS predict, round, clamp (high), Unmap, v = e + p, CalcError -> next stage inputs | barrier
 // then [D] Update of everything for both channels (all threads), and every k-th sample the Cholesky
@@ -100,6 +100,11 @@ __global__ __launch_bounds__(UN_NT) void k_unpredict(const UnJob *__restrict__ j
   // weights and gradient energies of the three smaller LMS stages ([w ch0, w ch1, eg ch0, eg ch1][tap]); only the
   // (1280,640) taps stay in registers
   __shared__ double lmM[4][LMS ? 384 : 1], lmS[4][64];
+  // LPC3::Predict on the matrix pipe: products sol[o][i]*hist[i] as a 24 x 24 table (row stride 25: the 16 chain lanes of
+  // an operand read on different banks; entries i > o stay +0, which leaves a sum that started at +0 unchanged),
+  // the products w[o]*ssum[o] of BlendErr::Predict, and (order << 8 | i) of every packed solution entry
+  __shared__ double prodL[LMS ? LPC_N * 25 : 1], prodP[LPC_N];
+  __shared__ uint16_t triL[LMS ? LPC_TRI : 1];
 
   const UnJob &job = jobs[blockIdx.x];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), n = job.n;  // wave: an SGPR, roles branch on it
@@ -120,32 +125,38 @@ __global__ __launch_bounds__(UN_NT) void k_unpredict(const UnJob *__restrict__ j
   // ---- per-thread state
   // (1280,640): wave s owns segment s (taps 128 s + 64 r + lane), for both channels
   double wB[2][2], gB[2][2];  // (the history values are read again from the rings in [D]: registers are short)
-  int offB[2];  // own: lag 1+i; other: j = i - 1280 (lag j + lagx of the channel)
+  // offB[r] (UN_FRESH): own: lag 1+i; other: j = i - 1280 (lag j + lagx of the channel), tap i = 128 wave + 64 r + lane
   const bool vB = BIG && wave < NSEG;
   const bool ownB = wave < SB / SEG;  // segments 0..9 hold the channel's own history, 10..14 the other channel's
   const double muB = ownB ? job.coef[1] : job.coef[2];
 #pragma unroll
-  for (int r = 0; r < 2; r++) {
-    const int i = SEG * wave + 64 * r + lane;
-    offB[r] = ownB ? 1 + i : i - SB;
-    wB[0][r] = wB[1][r] = gB[0][r] = gB[1][r] = 0.;
-  }
+  for (int r = 0; r < 2; r++) wB[0][r] = wB[1][r] = gB[0][r] = gB[1][r] = 0.;
   // (256,128): threads 0..383; (32,16): wave 15 lanes 0..47; (8,4): wave 15 lanes 48..59
-  const bool vM = LMS && tid < 384, vS = LMS && wave == 15 && lane < 48, vT = LMS && wave == 15 && lane >= 48 && lane < 60;
-  const int iT = lane - 48;
-  const bool ownM = wave < 4, ownS = lane < 32, ownT = iT < 8;
-  const int offM = ownM ? 1 + tid : tid - 256, offS = ownS ? 1 + lane : lane - 32, offT = ownT ? 1 + iT : iT - 8;
+  const bool ownM = wave < 4;
   const int cM = BIG ? 3 : 1;  // coefficient numbers (codec.cpp:8-30)
   const double muM = ownM ? job.coef[cM] : job.coef[cM + 1], muS = job.coef[cM + 2], muT = job.coef[cM + 3];
   if (LMS) for (int i = tid; i < 4 * 384; i += UN_NT) (&lmM[0][0])[i] = 0.;
   if (tid < 4 * 64) (&lmS[0][0])[tid] = 0.;  // (32,16) or (8,4) tap of wave 15
+  if (LMS) {
+    for (int i = tid; i < LPC_N * 25; i += UN_NT) prodL[i] = 0.;
+    for (int e = tid; e < LPC_TRI; e += UN_NT) {
+      int o = 0;
+      while ((o + 1) * (o + 2) / 2 <= e) o++;
+      triL[e] = (uint16_t)((o << 8) | (e - o * (o + 1) / 2));
+    }
+  }
   // AutoCov element (cov.h:13-51): threads 0..647, channel tid / 324
-  const int cch = tid / LPC_SNAP, ce = tid - cch * LPC_SNAP;
-  const bool vC = tid < 2 * LPC_SNAP, isc = ce < LPC_TRI;
-  int cj = 0, ci = 0;
-  if (isc) { while ((cj + 1) * (cj + 2) / 2 <= ce) cj++; ci = ce - cj * (cj + 1) / 2; }
-  else ci = ce - LPC_TRI;
-  double cv = (vC && isc && ci == cj) ? 1.0 : 0.0;  // cov.h:17
+  int cpack;  // ci | cj << 8 | channel << 16 | isc << 17 | valid << 18: one register across the loop
+  double cv;
+  {
+    const int cch = tid / LPC_SNAP, ce = tid - cch * LPC_SNAP;
+    const bool vC = tid < 2 * LPC_SNAP, isc = ce < LPC_TRI;
+    int cj = 0, ci = 0;
+    if (isc) { while ((cj + 1) * (cj + 2) / 2 <= ce) cj++; ci = ce - cj * (cj + 1) / 2; }
+    else ci = ce - LPC_TRI;
+    cv = (vC && isc && ci == cj) ? 1.0 : 0.0;  // cov.h:17
+    cpack = ci | (cj << 8) | (cch << 16) | ((int)isc << 17) | ((int)vC << 18);
+  }
   const double alpha = job.coef[0];
   // hist[i] of LPC channel ch at time t (cov.h:44-47 as indices): i < 16 own v(t-1-i), else other v(t - lagb - (i-16))
   auto lpc_h = [&](int ch, int i, int t) -> double {
@@ -156,21 +167,41 @@ __global__ __launch_bounds__(UN_NT) void k_unpredict(const UnJob *__restrict__ j
   for (int i = tid; i < 8 * 64; i += UN_NT) (&blS[0][0])[i] = 0.;
   for (int i = tid; i < 17 * 64; i += UN_NT) (&rlS[0][0])[i] = 0.;
   // RLS mixer (rls.cpp:61-108): wave 7, unit u = lane >> 4 = channel (units 2, 3 idle), lane (i, j) owns P[i][j]
-  const int ri = (lane >> 2) & 3, rj = lane & 3, ru = lane >> 4, base16 = lane & ~15;
-  const bool inm = ri < NS && rj < NS;
   __syncthreads();
-  if (wave == 7) rlS[0][lane] = (inm && ri == rj) ? 1. : 0.;  // P = I (rls.h)
+  if (wave == 7) {
+    const int ri = (lane >> 2) & 3, rj = lane & 3;
+    rlS[0][lane] = (ri < NS && rj < NS && ri == rj) ? 1. : 0.;  // P = I (rls.h)
+  }
   const double ralpha = LMS ? job.coef[BIG ? 7 : 5] : 1.;
   const double ria = 1. / ralpha;
-  const int mk = lane >> 4;  // MFMA operand lane: term 4s + mk at step s
+  // mk (UN_FRESH) = lane >> 4: MFMA operand lane, term 4s + mk at step s
   const int32_t mnv[2] = {job.minval[0], job.minval[1]}, mxv[2] = {job.maxval[0], job.maxval[1]};
   long long rounds = 0;
   __syncthreads();
+  // Values derived from the lane number are recomputed where a phase needs them, from a thread index the compiler cannot
+  // see through: hoisted out of the sample loop they (and the addresses built on them) filled the 128 registers a lane of
+  // a 1024-thread workgroup has, and every reload from scratch memory sat in front of a barrier the other waves wait at.
+#define UN_FRESH                                                                                                   \
+  int tid = threadIdx.x;                                                                                           \
+  asm volatile("" : "+v"(tid));                                                                                    \
+  const int lane = tid & 63;                                                                                       \
+  const int offB[2] = {ownB ? 1 + SEG * wave + lane : SEG * wave + lane - SB,                                      \
+                       ownB ? 1 + SEG * wave + 64 + lane : SEG * wave + 64 + lane - SB};                           \
+  const bool vM = LMS && wave < 6, vS = LMS && wave == 15 && lane < 48, vT = LMS && wave == 15 && lane >= 48 && lane < 60; \
+  const int iT = lane - 48;                                                                                        \
+  const bool ownS = lane < 32, ownT = iT < 8;                                                                      \
+  const int offM = ownM ? 1 + tid : tid - 256, offS = ownS ? 1 + lane : lane - 32, offT = ownT ? 1 + iT : iT - 8;  \
+  const int mk = lane >> 4;                                                                                        \
+  const int ri = (lane >> 2) & 3, rj = lane & 3, ru = lane >> 4, base16 = lane & ~15;                              \
+  (void)offB; (void)vM; (void)vS; (void)vT; (void)offM; (void)offS; (void)offT; (void)mk; (void)ri; (void)rj; (void)ru; (void)base16;
 #ifdef UN_PROF  // phase clocks of wave 0 (a participant of every barrier), written over the first samples of channel 0
   long long pfA = 0, pfB = 0, pfC = 0, pfD = 0, pfK = 0, pfT = clock64();
+  long long pwB = 0, pwD = 0;  // every wave: its own busy time in [B] and [D] (until it reaches the closing barrier)
 #define UN_TICK(acc) { const long long now_ = clock64(); acc += now_ - pfT; pfT = now_; }
+#define UN_BUSY(acc) { acc += clock64() - pfT; }
 #else
 #define UN_TICK(acc)
+#define UN_BUSY(acc)
 #endif
 
   for (int t = 0; t < n; t++) {
@@ -190,6 +221,7 @@ __global__ __launch_bounds__(UN_NT) void k_unpredict(const UnJob *__restrict__ j
       const int lagx = c == 0 ? 1 : 0;  // channel 0 sees the other channel up to t-1, channel 1 up to t (profile.cpp:128-132)
       // ---- [A] products w[i]*hist[i] (nlms.h:111)
       if constexpr (LMS) {
+        UN_FRESH
         if constexpr (BIG) {
           double part = 0.;
 #pragma unroll
@@ -231,16 +263,18 @@ __global__ __launch_bounds__(UN_NT) void k_unpredict(const UnJob *__restrict__ j
       // ---- [B] the strict left-to-right sums (nlms.h:110-111, lpc.h:190-199, blend.h:15-17). Waves 4..6 pass through
       // spec_exact_sum's barrier as bystanders first and sum while wave 0 walks and verifies (the (256,128) chain is as
       // long as walk + verification; in front of the barrier it would delay the walk)
+      {
+      UN_FRESH
       if constexpr (BIG) {
         const double res = spec_exact_sum<NSEG, SEG / 4, SEGP>((uint32_t)(uintptr_t)&prodsB[0], sJ, &sX1, sA, wave < 4 ? wave : -1,
-                                                               wave == 0, 0, rounds);
+                                                               wave == 0, 0, rounds, lane);
         if (wave == 0 && lane == 16 * ((NSEG - 1) & 3) + 4 * ((NSEG - 1) >> 2)) pst[1] = res;
       }
-      if (LMS && wave == 4) {
+      if (LMS && wave == 5) {  // SIMD 1 (waves go round the four SIMDs): wave 0's verification pass has SIMD 0's matrix pipe to itself
         const double acc = mfma_chain_lds<6>((uint32_t)(uintptr_t)&prodsM[mk]);
         if (lane == 0) pst[kM + 1] = acc;
       }
-      if (LMS && wave == 5) {
+      if (LMS && wave == 7) {
         double a3[12], a4[3], acc3 = 0., acc4 = 0.;
 #pragma unroll
         for (int u = 0; u < 12; u++) a3[u] = prodsS[4 * u + mk];
@@ -253,20 +287,46 @@ __global__ __launch_bounds__(UN_NT) void k_unpredict(const UnJob *__restrict__ j
         if (lane == 0) { pst[kS + 1] = acc3; pst[kT + 1] = acc4; }
       }
       if (wave == 6) {
-        if constexpr (LMS) {  // LPC3::Predict: all-orders sums, then BlendErr::Predict
-          double sum = 0.;
+        if constexpr (LMS) {  // LPC3::Predict: all-orders sums (lpc.h:190-199), then BlendErr::Predict (blend.h:13-17)
+          // A lane that keeps order `lane` to itself executes 24 dependent multiply-adds and 24 more for the blend at the
+          // single-wave FP64 issue rate (4k cycles: it bounded the phase). Instead: the 300 products, 5 per lane, into the
+          // table; the 24 sums are MFMA adder chains (B == 1: ((C + a0) + a1) + a2) + a3 per step, IEEE rounding after
+          // each add, terms in the reference's order i = 0, 1, ...), 16 orders per instruction, 6 steps.
 #pragma unroll
-          for (int i = 0; i < LPC_N; i++) {
-            const double h = lpc_h(c, i, t);
-            if (i <= lane && lane < LPC_N) sum += solL[c][lane * (lane + 1) / 2 + i] * h;
+          for (int q = 0; q < 5; q++) {
+            const int e = lane + 64 * q;
+            if (e < LPC_TRI) {
+              const int oi = triL[e], i = oi & 255;
+              prodL[(oi >> 8) * 25 + i] = solL[c][e] * lpc_h(c, i, t);
+            }
           }
-          blS[c][lane] = sum;
-          const double pr = blS[4 + c][lane] * sum;
-          double pm = 0.;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          const int r0 = (lane & 15) * 25 + mk, r1 = ((lane & 15) < 8 ? 16 + (lane & 15) : 23) * 25 + mk;  // orders 0..15 | 16..23 (rest: copies)
+          double a0[6], a1[6], acc0 = 0., acc1 = 0.;
 #pragma unroll
-          for (int i = 0; i < LPC_N; i++) pm += bcast(pr, i);
-          blS[6 + c][lane] = pm;
-          if (lane == 0) pst[0] = pm;
+          for (int u = 0; u < 6; u++) { a0[u] = prodL[r0 + 4 * u]; a1[u] = prodL[r1 + 4 * u]; }
+#pragma unroll
+          for (int u = 0; u < 6; u++) {
+            acc0 = __builtin_amdgcn_mfma_f64_4x4x4f64(a0[u], 1.0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_4x4x4f64(a1[u], 1.0, acc1, 0, 0, 0);
+          }
+          const int jD = 4 * ((lane >> 2) & 3) + (lane >> 4);  // chain of this D-layout lane
+          if ((lane & 3) == 0) {
+            blS[c][jD] = acc0;
+            if (jD < 8) blS[c][16 + jD] = acc1;
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          if (lane < LPC_N) prodP[lane] = blS[4 + c][lane] * blS[c][lane];
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          double ap[6], pm = 0.;
+#pragma unroll
+          for (int u = 0; u < 6; u++) ap[u] = prodP[4 * u + mk];
+#pragma unroll
+          for (int u = 0; u < 6; u++) pm = __builtin_amdgcn_mfma_f64_4x4x4f64(ap[u], 1.0, pm, 0, 0, 0);
+          if (lane == 0) { pst[0] = pm; blS[6 + c][LPC_N] = pm; }  // slot LPC_N: the error of the blend itself (blend.h:38)
         } else {  // LPC2::Predict (lpc.h:261-267)
           double p = 0.;
 #pragma unroll
@@ -274,10 +334,13 @@ __global__ __launch_bounds__(UN_NT) void k_unpredict(const UnJob *__restrict__ j
           if (lane == 0) pst[0] = p;
         }
       }
+      }
+      UN_BUSY(pwB)
       __syncthreads();
       UN_TICK(pfB)
       // ---- [C] mix, round, unmap, reconstruct, CalcError (profile.cpp:134-148, 161-174)
       if (wave == 7) {
+        UN_FRESH
         const int32_t e_in = ebuf[c][t & (UN_IO - 1)];
         int32_t v;
         double val[NS + 1];
@@ -318,6 +381,8 @@ __global__ __launch_bounds__(UN_NT) void k_unpredict(const UnJob *__restrict__ j
       UN_TICK(pfC)
     }
     // ---- [D] Update (profile.cpp:102-111, 176-186)
+    {
+    UN_FRESH
     if constexpr (LMS) {
 #pragma unroll
       for (int c = 0; c < 2; c++) {
@@ -398,25 +463,30 @@ __global__ __launch_bounds__(UN_NT) void k_unpredict(const UnJob *__restrict__ j
         for (int k = 0; k < NS; k++) rlS[1 + k][lane] = rlS[1 + k][lane] + dv * kk[k];
       }
     }
+    const int ci = cpack & 255, cj = (cpack >> 8) & 255, cch = (cpack >> 16) & 1;
+    const bool isc = (cpack >> 17) & 1, vC = (cpack >> 18) & 1;
     if (vC) {  // AutoCov::UpdateCov / UpdateB (cov.h:19-43)
       const double hi = lpc_h(cch, ci, t);
       const double hj = isc ? lpc_h(cch, cj, t) : vh[cch][t & 63];
       if (isc) cv = alpha * cv + (hi * hj);
       else cv = alpha * cv + (hj * hi);
     }
+    UN_BUSY(pwD)
     UN_TICK(pfD)
     if (((t + 1) % KS) == 0) {  // lpc.h:213-219 / :277-283
-      if (vC) snapL[cch][ce] = cv;
+      if (vC) snapL[cch][tid - cch * LPC_SNAP] = cv;
       __syncthreads();
       if (wave < 2) chol_wave_call<TYPE == 0>(snapL[wave], solL[wave], lane);  // "matrix indefinit": the previous solution stays
       __syncthreads();
       UN_TICK(pfK)
+    }
     }
   }
   __syncthreads();
 #ifdef UN_PROF
   if (tid == 0 && n >= 256) { vbuf[0][0] = (int32_t)(pfA >> 10); vbuf[0][1] = (int32_t)(pfB >> 10); vbuf[0][2] = (int32_t)(pfC >> 10);
     vbuf[0][3] = (int32_t)(pfD >> 10); vbuf[0][4] = (int32_t)(pfK >> 10); }
+  if (lane == 0 && n >= 256) { vbuf[1][wave] = (int32_t)(pwB >> 10); vbuf[1][16 + wave] = (int32_t)(pwD >> 10); }
   __syncthreads();
 #endif
   if (n > 0) {
