@@ -1300,8 +1300,13 @@ extern "C" int sacopt_unpredict_stereo_frames(sacopt_ctx *c, int profile, int nf
   HIPCK(c, hipEventCreate(&a));
   HIPCK(c, hipEventCreate(&b));
   HIPCK(c, hipEventRecord(a, c->st));
-  if (sacopt_launch_unpredict(profile, dj, nframes, c->d_tab, c->bits, c->st)) { c->err = "k_unpredict launch failed"; return 1; }
-  HIPCK(c, hipEventRecord(b, c->st));
+  // one workgroup per frame, a CU each: launch on the stream that may use every CU (c->st leaves out the CUs reserved for
+  // the encoder's lead stage), ordered behind the uploads and in front of the copies by events
+  hipStream_t ks = c->sAall ? c->sAall : c->st;
+  if (ks != c->st) HIPCK(c, hipStreamWaitEvent(ks, a, 0));
+  if (sacopt_launch_unpredict(profile, dj, nframes, c->d_tab, c->bits, ks)) { c->err = "k_unpredict launch failed"; return 1; }
+  HIPCK(c, hipEventRecord(b, ks));
+  if (ks != c->st) HIPCK(c, hipStreamWaitEvent(c->st, b, 0));
   c->lms_ev.push_back({a, b});
   for (int f = 0; f < nframes; f++) {
     const size_t bytes = (size_t)frames[f].numsamples * 4;

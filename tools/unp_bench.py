@@ -8,7 +8,8 @@ from sac_amd.synth import stereo_clip
 nfr = int(sys.argv[1]) if len(sys.argv) > 1 else 15
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 176400
 ctx = sacopt.Context(0)
-clips = [stereo_clip(1 + i, n) for i in range(nfr)]
+base = [stereo_clip(1 + i, n) for i in range(min(nfr, 4))]
+clips = [base[i % len(base)] for i in range(nfr)]
 for prof in (0, 1, 2):
     enc = ctx.predict(prof, clips)
     t = time.time()
