@@ -109,3 +109,41 @@ def test_optimised_parameters_round_trip(ctx):
     if not np.array_equal(best[0], sacopt.base_profile(2)[:, 2]):
         wrong = ctx.unpredict(2, [dict(e0=enc[0]["e0"], e1=enc[0]["e1"])])[0]
         assert not np.array_equal(wrong[0], frames[0][0])
+
+
+# ---------------------------------------------------------------- BASELINE sizes: encode -> decode round trips
+def test_full_size_round_trip_44k(ctx):
+    # BASELINE configs[1..3] frame size (176400 = 4 s @ 44.1 kHz), every profile: FrameCoder::Predict (optimizer off, Remap
+    # outputs on) then UnpredictStereoFrame restores the samples; channel 1 goes through Remap::Map / Unmap
+    n = 176400
+    frames = [stereo_clip(310, n), stereo_clip(311, n)]
+    for prof in (0, 1, 2):
+        _, enc = ctx.encode(prof, frames, ncoef_loop=0, maps=True)
+        dec_in = []
+        for (L, R), d in zip(frames, enc):
+            m1 = np.where(d["m1"] & 1, (d["m1"].astype(np.int64) + 1) >> 1, -(d["m1"].astype(np.int64) >> 1)).astype(np.int32)
+            used1 = np.zeros(2 * 32769, np.uint8)  # Remap::Analyse of channel 1 (map.cpp:111-130)
+            used1[32769 + R[(R > 0) & (R <= 32768)]] = 1
+            used1[-R[(R < 0) & (R >= -32768)]] = 1
+            if prof == 0:
+                dec_in.append(dict(e0=d["e0"], e1=d["e1"]))  # StereoFast::Unpredict never unmaps (profile.cpp:34-43)
+            else:
+                dec_in.append(dict(e0=d["e0"], e1=m1, used1=used1))
+        dec = ctx.unpredict(prof, dec_in)
+        for (L, R), v in zip(frames, dec):
+            assert np.array_equal(v[0], L) and np.array_equal(v[1], R), prof
+
+
+def test_full_size_round_trip_config5(ctx):
+    # BASELINE configs[4] shape: 24-bit 96 kHz, 8 channels = 4 stereo pairs, framesize 384000 (4 s): each pair is a frame
+    # of the batch; high profile, encode with per-pair parameters, decode with the same
+    n = 384000
+    frames = [stereo_clip(320 + k, n, rate=96000, bits=24) for k in range(4)]
+    assert max(int(np.abs(f[0]).max()) for f in frames) > (1 << 20)
+    base = sacopt.base_profile(2)[:, 2]
+    coefs = np.tile(base, (4, 1))
+    coefs[1, 0] = 0.9985; coefs[2, 1] = 2e-5; coefs[3, 7] = 0.9995
+    enc = ctx.predict(2, frames, coefs=coefs)
+    dec = ctx.unpredict(2, [dict(e0=d["e0"], e1=d["e1"]) for d in enc], coefs=coefs)
+    for (L, R), v in zip(frames, dec):
+        assert np.array_equal(v[0], L) and np.array_equal(v[1], R)
