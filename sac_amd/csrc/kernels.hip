@@ -281,10 +281,11 @@ __device__ __forceinline__ double spec_exact_sum(uint32_t prods_addr, int (*sJ)[
 // ------------------------------------------------------------------------------------------
 #define L1_SEG 128   // products per segment (32 MFMA steps)
 #define L1_SEGP 130  // segment stride in LDS: the 16 chain lanes of a ds_read_b64 half on 16 different 4-bank groups
-template <int S, int D, int NT, int R, int RL, bool SPEC>
+template <int S, int D, int NT, int R, int RL, bool SPEC, int CHP = LMS_CHUNK>
 __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, const uint16_t *__restrict__ gtab,
                                             int bits) {
-  constexpr int T = S + D, T4 = T / 4, M = RL - 1, CH = LMS_CHUNK;
+  constexpr int T = S + D, T4 = T / 4, M = RL - 1, CH = CHP;  // CH: samples staged per refill (divides LMS_CHUNK, the unit of the host's chunk edges)
+  static_assert(LMS_CHUNK % CHP == 0, "refill size must divide LMS_CHUNK");
   // SPEC: 15 segments of 128 products, padded to a stride of 130 doubles so that the 16 segment
   // lanes of a ds_read_b64 half fall on 16 different 4-bank groups
   constexpr int SEG = L1_SEG, SEGP = L1_SEGP, NSEG = 15, TP = SPEC ? 16 * SEGP : T + 4;  // T + 4: the two channels' MFMA operands on different banks
@@ -299,7 +300,7 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
   // sample would put an HBM write round trip in front of every barrier)
   __shared__ double pbuf[2][CH];
   // speculative exact summation (SPEC): boundary tables of spec_exact_sum, per channel
-  __shared__ int sJ[2][16][16];
+  __shared__ int sJ[2][SPEC ? 16 : 1][16];
   __shared__ double sX1[2];
   __shared__ double sA[2][16];  // SPEC: approximate segment sums (the guess of spec_exact_sum)
   __shared__ uint16_t tab[RSQ_LDS_MAX];
@@ -1292,9 +1293,17 @@ extern "C" int sacopt_launch_lms(int S, int D, const LmsJob *jobs, int njobs, co
     else if ((bits >> 8) & 4096) hipLaunchKernelGGL((k_lms<1280, 640, 1024, 4, 2048, true>), dim3(njobs), dim3(1024), 0, st, jobs, tab, bits);
     else hipLaunchKernelGGL((k_lms<1280, 640, 512, 8, 2048, true>), dim3(njobs), dim3(512), 0, st, jobs, tab, bits);
   }
-  else if (S == 256 && D == 128) hipLaunchKernelGGL((k_lms<256, 128, 256, 3, 1024, false>), dim3(njobs), dim3(256), 0, st, jobs, tab, bits);
-  else if (S == 32 && D == 16) hipLaunchKernelGGL((k_lms<32, 16, 64, 2, 1024, false>), dim3(njobs), dim3(64), 0, st, jobs, tab, bits);
-  else if (S == 8 && D == 4) hipLaunchKernelGGL((k_lms<8, 4, 64, 1, 1024, false>), dim3(njobs), dim3(64), 0, st, jobs, tab, bits);
+  // follower stages: short rings (128 samples per refill) keep their LDS small, so that more of them share a CU and
+  // fit beside a lead workgroup (A/B switch 8192: the 512-sample instances)
+  else if ((bits >> 8) & 8192) {
+    if (S == 256 && D == 128) hipLaunchKernelGGL((k_lms<256, 128, 256, 3, 1024, false>), dim3(njobs), dim3(256), 0, st, jobs, tab, bits);
+    else if (S == 32 && D == 16) hipLaunchKernelGGL((k_lms<32, 16, 64, 2, 1024, false>), dim3(njobs), dim3(64), 0, st, jobs, tab, bits);
+    else if (S == 8 && D == 4) hipLaunchKernelGGL((k_lms<8, 4, 64, 1, 1024, false>), dim3(njobs), dim3(64), 0, st, jobs, tab, bits);
+    else return 1;
+  }
+  else if (S == 256 && D == 128) hipLaunchKernelGGL((k_lms<256, 128, 256, 3, 512, false, 128>), dim3(njobs), dim3(256), 0, st, jobs, tab, bits);
+  else if (S == 32 && D == 16) hipLaunchKernelGGL((k_lms<32, 16, 64, 2, 256, false, 128>), dim3(njobs), dim3(64), 0, st, jobs, tab, bits);
+  else if (S == 8 && D == 4) hipLaunchKernelGGL((k_lms<8, 4, 64, 1, 256, false, 128>), dim3(njobs), dim3(64), 0, st, jobs, tab, bits);
   else return 1;
   return hipGetLastError() != hipSuccess;
 }
