@@ -55,8 +55,12 @@ static float rsqrt_table(const float *tab, int bits, float x) {
   return r;
 }
 
-void oracle_set_rsqrt_table(const float *tab, int bits) {
-  g_tab = tab;
+void oracle_set_rsqrt_table(const float *tab, int bits) { /* the table is copied: the caller's buffer may go away */
+  static float copy[1 << 14];
+  if (tab && bits >= 0 && bits <= 13) {
+    memcpy(copy, tab, sizeof(float) * ((size_t)2 << bits));
+    g_tab = copy;
+  } else g_tab = 0;
   g_bits = bits;
 }
 
