@@ -147,3 +147,24 @@ def test_full_size_round_trip_config5(ctx):
     dec = ctx.unpredict(2, [dict(e0=d["e0"], e1=d["e1"]) for d in enc], coefs=coefs)
     for (L, R), v in zip(frames, dec):
         assert np.array_equal(v[0], L) and np.array_equal(v[1], R)
+
+
+def test_unpredict_error_paths(ctx):
+    # non-zero status + message, nothing thrown across the ABI (INTEGRATION.md "Error behaviour")
+    import ctypes as C
+    L = sacopt.lib()
+    arr = (sacopt.DecFrame * 1)()
+    arr[0].numsamples = 16  # null residual / sample pointers
+    assert L.sacopt_unpredict_stereo_frames(ctx._h, 2, 1, arr, None) != 0
+    assert b"bad frame" in L.sacopt_last_error(ctx._h)
+    assert L.sacopt_unpredict_stereo_frames(ctx._h, 7, 1, arr, None) != 0
+    assert b"unknown profile" in L.sacopt_last_error(ctx._h)
+    arr[0].numsamples = -1
+    assert L.sacopt_unpredict_stereo_frames(ctx._h, 2, 1, arr, None) != 0
+    assert L.sacopt_unpredict_stereo_frames(ctx._h, 2, 0, None, None) == 0  # no frames: nothing to do
+    assert L.sacopt_unpredict_stereo_frames(None, 2, 0, None, None) != 0    # no context
+    # the context is still usable after the failures
+    Ls, Rs = stereo_clip(95, 300)
+    e = ctx.predict(0, [(Ls, Rs)])[0]
+    v = ctx.unpredict(0, [dict(e0=e["e0"], e1=e["e1"])])[0]
+    assert np.array_equal(v[0], Ls) and np.array_equal(v[1], Rs)
