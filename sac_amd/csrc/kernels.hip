@@ -59,8 +59,7 @@ __device__ __forceinline__ double bcast(double v, int srclane) {
 // unused data (still inside the workgroup's LDS allocation: the ring follows the products).
 #define MF(areg) "v_mfma_f64_4x4x4_4b_f64 %0, " areg ", %2, %0\n s_nop 3\n"
 template <int ITER>
-__device__ __forceinline__ double mfma_chain_lds(uint32_t addr) {
-  double acc = 0.;
+__device__ __forceinline__ double mfma_chain_lds(uint32_t addr, double acc = 0.) {  // acc: this D-layout lane's start value
   double one = 1.0;
   double a0, a1, a2, a3, a4, a5, a6, a7, b0, b1, b2, b3, b4, b5, b6, b7;
   uint32_t cnt;
@@ -281,6 +280,9 @@ __device__ __forceinline__ double spec_exact_sum(uint32_t prods_addr, int (*sJ)[
 // ------------------------------------------------------------------------------------------
 #define L1_SEG 128   // products per segment (32 MFMA steps)
 #define L1_SEGP 130  // segment stride in LDS: the 16 chain lanes of a ds_read_b64 half on 16 different 4-bank groups
+#ifndef LMS_HALVES_WAVES
+#define LMS_HALVES_WAVES 2  // candidate waves of the (256,128) stage's second half: 32 candidates per channel each
+#endif
 template <int S, int D, int NT, int R, int RL, bool SPEC, int CHP = LMS_CHUNK>
 __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, const uint16_t *__restrict__ gtab,
                                             int bits) {
@@ -304,6 +306,14 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
   __shared__ double sX1[2];
   __shared__ double sA[2][16];  // SPEC: approximate segment sums (the guess of spec_exact_sum)
   __shared__ uint16_t tab[RSQ_LDS_MAX];
+  // HALVES (the (256,128) stage): the 384-term chain of a channel is cut in two. Wave 0 sums the first half exactly from
+  // +0 while waves 1 and 2 sum the second half from 2 x 32 candidate inputs per channel around a guess of the first half's sum
+  // (rows of the MFMA = channel x 8 candidate groups, its 4 output columns keep their own C: 64 accumulators = 2 x 32
+  // candidates in ONE chain of 48 steps per wave). If the exact first half IS one of the candidates, bit for bit, that candidate's
+  // output is the exact left-to-right sum of all 384 terms; if not, wave 0 sums the second half from the exact value
+  // (48 more steps, as long as the undivided chain). Exactness never rests on the guess.
+  constexpr bool HALVES = !SPEC && T == 384;
+  __shared__ double hX1[2], hStart[2][64], hOut[2][64], hGb[2], hIu[2], hP2[2];
 
   const LmsJob job = jobs[blockIdx.x];
   const int tid = threadIdx.x, t0 = job.t0, tend = job.t0 + job.n;
@@ -376,8 +386,10 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
       }
     }
   };
+  long long hmiss = 0;
   for (int t = t0; t < tend; t++) {
     if ((t & (CH - 1)) == 0) {
+      if (HALVES) __syncthreads();  // the last prediction went to pbuf after the sample's last barrier
       if (t > t0) flush(t - CH, t);
       for (int idx = tid; idx < 2 * CH; idx += NT) {
         const int c = idx / CH, k = idx - c * CH, tau = t + k;
@@ -420,6 +432,76 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
         predv[sc] = res;
         pbuf[sc][t & (CH - 1)] = res;
       }
+    } else if constexpr (HALVES) {
+      constexpr int H = T / 2;  // 192 terms = 48 steps
+      if (wave == 0) {
+        const double acc = mfma_chain_lds<3>((uint32_t)(uintptr_t)mp);
+        if (lane == 0 || lane == 16) hX1[lane >> 4] = acc;
+      } else if (wave >= 1 && wave <= LMS_HALVES_WAVES) {  // 32 candidates per channel each: offsets -32..-1 and 0..31 ulps from the guess
+        double g0 = (prods[0][lane] + prods[0][64 + lane]) + prods[0][128 + lane];  // any order: only a guess
+        double g1 = (prods[1][lane] + prods[1][64 + lane]) + prods[1][128 + lane];
+        {  // wave sums by DPP: 16-lane rows, then row 0 -> 1 and 2 -> 3, then rows 0..1 -> 2..3: lane 63 has the total
+          double gg[2] = {g0, g1};
+#pragma unroll
+          for (int q = 0; q < 2; q++) {
+            double v = row_prefix16(gg[q]);
+            int lo = __double2loint(v), hi = __double2hiint(v);
+            lo = __builtin_amdgcn_update_dpp(0, lo, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1 and 3
+            hi = __builtin_amdgcn_update_dpp(0, hi, 0x142, 0xA, 0xF, false);
+            v += __hiloint2double(hi, lo);
+            lo = __double2loint(v); hi = __double2hiint(v);
+            lo = __builtin_amdgcn_update_dpp(0, lo, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2 and 3
+            hi = __builtin_amdgcn_update_dpp(0, hi, 0x143, 0xC, 0xF, false);
+            v += __hiloint2double(hi, lo);
+            gg[q] = bcast(v, 63);
+          }
+          g0 = gg[0]; g1 = gg[1];
+        }
+        // D-layout lane: chain 4*blk + i (i = lane >> 4, blk = (lane >> 2) & 3), column lane & 3; chain & 1 = channel
+        const int i = lane >> 4, blk = (lane >> 2) & 3, chD = i & 1, m = 32 * (wave - 1) + 8 * blk + 4 * (i >> 1) + (lane & 3);
+        const double g = chD ? g1 : g0;
+        double iu;
+        const double u = ulp_pow2(g, &iu);
+        const double stv = (g - 16. * LMS_HALVES_WAVES * u) + (double)m * u;
+        const double out = mfma_chain_lds<3>((uint32_t)(uintptr_t)(mp + H), stv);
+        hStart[chD][m] = stv;
+        hOut[chD][m] = out;
+        if (m == 0) { hGb[chD] = stv; hIu[chD] = iu; }
+      }
+      __syncthreads();
+      double pr[2];
+      bool miss = false;
+#pragma unroll
+      for (int c = 0; c < 2; c++) {
+        const double x1 = hX1[c];
+        int mi = (int)((x1 - hGb[c]) * hIu[c]);
+        mi = mi < 0 ? 0 : (mi > 32 * LMS_HALVES_WAVES - 1 ? 32 * LMS_HALVES_WAVES - 1 : mi);
+        if (__double_as_longlong(hStart[c][mi]) == __double_as_longlong(x1)) pr[c] = hOut[c][mi];
+        else miss = true;
+      }
+      if (miss) {  // uniform: every thread read the same values
+        hmiss++;
+        if (wave == 0) {
+          const double acc = mfma_chain_lds<3>((uint32_t)(uintptr_t)(mp + H), hX1[(lane >> 4) & 1]);
+          if (lane == 0 || lane == 16) hP2[lane >> 4] = acc;
+        }
+        __syncthreads();
+        pr[0] = hP2[0]; pr[1] = hP2[1];
+      }
+      if (tid < 2) pbuf[tid][t & (CH - 1)] = tid ? pr[1] : pr[0];
+      // ---- Update (nlms.h:114-129)
+      const double e0 = ring[0][t & M] - pr[0];
+      const double e1 = ring[1][t & M] - pr[1];
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        if (valid[r] && !(dbg & 2)) {
+          const double err = cs[r] ? e1 : e0;
+          const double grad = err * h[r];
+          eg[r] = 0.95 * eg[r] + (1.0 - 0.95) * (grad * grad);
+          w[r] += (mu[r] * grad * rsq_emul(eg[r] + 0.001, tab, bits));
+        }
+      }
+      continue;
     } else
     if (wave == 0) {
       double acc = 0.;
@@ -453,7 +535,12 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
       }
     }
   }
+  if (HALVES) __syncthreads();
   if (tend > t0) flush((tend - 1) & ~(CH - 1), tend);
+  if (HALVES && (dbg & 128)) {  // DEBUG: samples whose first half missed the candidates
+    __syncthreads();
+    if (tid == 0) job.p[0][t0] = (double)hmiss;
+  }
   if (job.state) {
 #pragma unroll
     for (int r = 0; r < R; r++)
