@@ -430,7 +430,7 @@ static int lpc_scratch_alloc(sacopt_ctx *c, int type, LpcJob &j) {
 #define PIPE_CHUNK (16 * LMS_CHUNK) /* 8192 samples */
 // job tables + carried state of the pipelined pass for one chain of n samples
 static size_t pipe_bytes(int n) {
-  const size_t nchunk = (size_t)n / PIPE_CHUNK + 1;
+  const size_t nchunk = (size_t)n / PIPE_CHUNK + 20;  // + the short first chunk and the halving tail
   return nchunk * (4 * (sizeof(LmsJob) + 256) + sizeof(MixJob) + 256 + sizeof(LpcJob) + 256) + 16 * 1024 * 8 + 16384;
 }
 
@@ -683,7 +683,23 @@ static int final_pass_enqueue(sacopt_ctx *c, const ProfDesc &pd, const std::vect
       ch.sb[s] = b;
     }
   }
-  const int nchunk = (max_n + PIPE_CHUNK - 1) / PIPE_CHUNK;
+  // Chunk edges (multiples of LMS_CHUNK): a short first chunk -- its LPC stage is the only work in front of the lead
+  // stage -- then PIPE_CHUNK samples each, and a tail that halves down to 2 * LMS_CHUNK: what remains after the lead stage's
+  // last launch is the follower stages of the LAST chunk only.
+  std::vector<int> edges = {0};
+  {
+    int t = 0;
+    if (max_n > 4 * PIPE_CHUNK) { t = 2 * LMS_CHUNK; edges.push_back(t); }
+    while (max_n - t > PIPE_CHUNK + PIPE_CHUNK / 2) { t += PIPE_CHUNK; edges.push_back(t); }
+    while (max_n - t > 2 * LMS_CHUNK) {
+      const int rem = max_n - t;
+      t += ((rem / 2 + LMS_CHUNK - 1) / LMS_CHUNK) * LMS_CHUNK;
+      edges.push_back(t);
+    }
+    if (t < max_n || edges.size() == 1) edges.push_back(max_n);
+  }
+  const int nchunk = (int)edges.size() - 1;
+  auto chunk_end = [&](int k, int n) { return n < edges[k + 1] ? n : edges[k + 1]; };
   // ---- all job tables, built and uploaded up front
   std::vector<LpcJob> lpc(nch);
   for (int i = 0; i < nch; i++) {
@@ -704,14 +720,14 @@ static int final_pass_enqueue(sacopt_ctx *c, const ProfDesc &pd, const std::vect
   std::vector<LpcJob *> d_lpc(nchunk, nullptr);
   std::vector<int> n_lpc(nchunk, 0), len_lpc(nchunk, 0);
   for (int k = 0; k < nchunk; k++) {
-    const int t0 = k * PIPE_CHUNK;
+    const int t0 = edges[k];
     std::vector<LpcJob> jobs;
     for (int i = 0; i < nch; i++) {
       const int n = fr[chains[i].frame].n;
       if (t0 >= n) continue;
       LpcJob j = lpc[i];
       j.t0 = t0;
-      j.n = (n - t0 < PIPE_CHUNK) ? n : t0 + PIPE_CHUNK;
+      j.n = chunk_end(k, n);
       j.nsnap = j.n / 8;
       len_lpc[k] = (j.n - t0 > len_lpc[k]) ? j.n - t0 : len_lpc[k];
       jobs.push_back(j);
@@ -735,7 +751,7 @@ static int final_pass_enqueue(sacopt_ctx *c, const ProfDesc &pd, const std::vect
     if (!mix_state[i]) { c->err = "device arena exhausted"; return 1; }
   }
   for (int k = 0; k < nchunk; k++) {
-    const int t0 = k * PIPE_CHUNK;
+    const int t0 = edges[k];
     for (int q = 0; q < pd.nlms; q++) {
       std::vector<LmsJob> jobs;
       for (int i = 0; i < nch; i++) {
@@ -747,7 +763,7 @@ static int final_pass_enqueue(sacopt_ctx *c, const ProfDesc &pd, const std::vect
         j.mu1 = ch.coefs[pd.lms[q].c1];
         j.mu2 = ch.coefs[pd.lms[q].c2];
         j.t0 = t0;
-        j.n = (n - t0 < PIPE_CHUNK) ? n - t0 : PIPE_CHUNK;
+        j.n = chunk_end(k, n) - t0;
         j.state = lms_state[q][i];
         jobs.push_back(j);
         if (q == 0) units[k] += j.n;
@@ -773,7 +789,7 @@ static int final_pass_enqueue(sacopt_ctx *c, const ProfDesc &pd, const std::vect
       j.umax = ch.sb[last].umax;
       j.alpha = ch.coefs[pd.cmix];
       j.t0 = t0;
-      j.n = (f.n - t0 < PIPE_CHUNK) ? f.n - t0 : PIPE_CHUNK;
+      j.n = chunk_end(k, f.n) - t0;
       j.state = mix_state[i];
       jobs.push_back(j);
     }
