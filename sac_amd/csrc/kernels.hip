@@ -1363,11 +1363,14 @@ extern "C" int sacopt_lms_state_doubles(int S, int D) {  // 2 * R * NT of the ma
   if (S == 8 && D == 4) return 2 * 1 * 64;
   return 0;
 }
-// Which kernel a (1280,640) launch of `njobs` chains uses: 1 = k_lms1c (one workgroup per channel, while that
-// still leaves every workgroup a CU of its own), 0 = k_lms<1280,640,...> (one workgroup per chain).
+// Which kernel a (1280,640) launch of `njobs` chains uses: 1 = k_lms1c (one workgroup per channel), 0 = k_lms<1280,640,...>
+// (one workgroup per chain). k_lms1c is faster per chain (7.0k against 10k cycles per sample) but takes two CUs for it
+// (14k against 10k CU-cycles): right while the call is bound by the latency of a few chains (the 60 s clip: 15), wrong once
+// the optimizer's rounds fill the chip (measured, frames per call: 24: 888 against 860 ms, 30: 1036 against 922, 75: 2130
+// against 2020 with the two-channel kernel everywhere).
 extern "C" int sacopt_lms_variant(int S, int D, int njobs, int bits) {
   if (S != 1280 || D != 640) return 0;
-  return (!((bits >> 8) & (8 | 256)) && (njobs <= 100 || ((bits >> 8) & 512))) ? 1 : 0;
+  return (!((bits >> 8) & (8 | 256)) && (njobs <= 20 || ((bits >> 8) & 512))) ? 1 : 0;
 }
 extern "C" int sacopt_launch_lms(int S, int D, const LmsJob *jobs, int njobs, const uint16_t *tab, int bits,
                                  hipStream_t st) {

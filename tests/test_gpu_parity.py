@@ -193,8 +193,8 @@ def test_frame_records_byte_identical():
 
 
 def test_predict_many_frames_kernel_variants(ctx, oracle):
-    # > 100 chains per launch use the two-channel LMS(1280,640) kernel, fewer use the per-channel one;
-    # with ragged lengths the later pipeline chunks drop below 100 jobs, so a chain's carried state
+    # > 20 chains per launch use the two-channel LMS(1280,640) kernel, fewer use the per-channel one;
+    # with ragged lengths the later pipeline chunks drop below 20 jobs, so a chain's carried state
     # passes from one kernel to the other. Everything must equal the one-frame-at-a-time results
     # (per-channel kernel only) and, for sampled frames, the oracle.
     lens = [16500 + 37 * i for i in range(98)] + [24600 + 11 * i for i in range(8)]
