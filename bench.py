@@ -209,6 +209,13 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()
+            try:  # frame-parallel on the box's CPU share (16 cores), as its own process: SURVEY §8d (ii)
+                import subprocess
+                out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cpu_baseline_mc.py"), "16", "32768"],
+                                     capture_output=True, text=True, timeout=180)
+                line["cpu_baseline_all_cores"] = json.loads(out.stdout.strip().splitlines()[-1])
+            except Exception as e:  # a reported baseline, never the measurement
+                line["cpu_baseline_all_cores"] = {"error": str(e)[:200]}
         if not args.no_large_batch and world == 1 and nfr == NFRAMES:
             line["large_batch"] = large_batch_extra(ctx, torch, dev, stereo_clip, sacopt)   # untimed extra, not `value`
         if not args.no_decode and world == 1:
