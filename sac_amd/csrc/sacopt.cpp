@@ -41,6 +41,7 @@ struct sacopt_ctx {
   hipStream_t st = nullptr;
   hipStream_t sA = nullptr, sB = nullptr;  // final-pass pipeline: dominant LMS stage / everything else
   hipStream_t sC = nullptr;                // follower stages of the optimizer rounds
+  hipStream_t sE = nullptr;                // optimizer followers behind the first one (may be NULL: all on sC)
   hipStream_t sAall = nullptr;             // lead stage of the full-frame pass when it has more workgroups than sA's reserved CUs
   hipStream_t sD = nullptr;                // final-pass pipeline: stages behind the second LMS stage (may be NULL)
   std::vector<hipEvent_t> pipe_ev;         // events of the last call's pipeline
@@ -227,7 +228,8 @@ extern "C" int sacopt_create(int device, const float *rsqrt_tab, int rsqrt_bits,
                hipExtStreamCreateWithCUMask(&c->st, words, mr.data()) == hipSuccess &&
                hipExtStreamCreateWithCUMask(&c->sB, words, mr.data()) == hipSuccess &&
                hipExtStreamCreateWithCUMask(&c->sC, words, mr.data()) == hipSuccess &&
-               hipExtStreamCreateWithCUMask(&c->sD, words, mr.data()) == hipSuccess;
+               hipExtStreamCreateWithCUMask(&c->sD, words, mr.data()) == hipSuccess &&
+               hipExtStreamCreateWithCUMask(&c->sE, words, mr.data()) == hipSuccess;
       if (masked) {
         std::vector<uint32_t> mall(mr);
         mall[0] = 0xffffffffu;
@@ -235,7 +237,7 @@ extern "C" int sacopt_create(int device, const float *rsqrt_tab, int rsqrt_bits,
       }
       if (!masked) {
         (void)hipGetLastError();
-        hipStream_t *all[6] = {&c->sA, &c->st, &c->sB, &c->sC, &c->sD, &c->sAall};
+        hipStream_t *all[7] = {&c->sA, &c->st, &c->sB, &c->sC, &c->sD, &c->sAall, &c->sE};
         for (hipStream_t *p : all) if (*p) { (void)hipStreamDestroy(*p); *p = nullptr; }
       }
     }
@@ -283,6 +285,7 @@ extern "C" void sacopt_destroy(sacopt_ctx *c) {
   if (c->sC) (void)hipStreamDestroy(c->sC);
   if (c->sD) (void)hipStreamDestroy(c->sD);
   if (c->sAall) (void)hipStreamDestroy(c->sAall);
+  if (c->sE) (void)hipStreamDestroy(c->sE);
   if (c->st) (void)hipStreamDestroy(c->st);
   delete c;
 }
@@ -339,7 +342,7 @@ static int begin_call(sacopt_ctx *c) {
   HIPCK(c, hipSetDevice(c->device));
   c->err.clear();
   // a call that failed half-way may have left work in flight on the pipeline streams; the arena is about to be reused
-  for (hipStream_t s : {c->st, c->sA, c->sAall, c->sB, c->sC, c->sD})
+  for (hipStream_t s : {c->st, c->sA, c->sAall, c->sB, c->sC, c->sD, c->sE})
     if (s) HIPCK(c, hipStreamSynchronize(s));
   for (auto &p : c->lms_ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   c->lms_ev.clear();
@@ -604,9 +607,11 @@ static int eval_chains(sacopt_ctx *c, const ProfDesc &pd, const std::vector<DevF
         d_jobs[s] = dj;
       }
     }
-    // ---- launches: lead stage on c->st, followers on c->sC behind an event
+    // ---- launches: lead stage on c->st, the first follower on c->sC, the others on c->sE, each behind an event: three
+    // pipeline stages per chunk (one follower stream ran (32,16), (8,4) and the mixer of a chunk back to back, as long as
+    // an lms2 lead chunk: the followers fell behind and left a tail of three chunks after the lead's last one)
     for (int s = lead; s < nstage; s++) {
-      hipStream_t st = (s == lead) ? c->st : c->sC;
+      hipStream_t st = (s == lead) ? c->st : ((s == lead + 1 || !c->sE) ? c->sC : c->sE);
       if (n_jobs[s]) {
         if (s <= pd.nlms) {
           const StageDesc &sd = pd.lms[s - 1];
@@ -635,12 +640,20 @@ static int eval_chains(sacopt_ctx *c, const ProfDesc &pd, const std::vector<DevF
         HIPCK(c, hipEventRecord(e, c->st));
         HIPCK(c, hipStreamWaitEvent(c->sC, e, 0));
       }
+      if (s == lead + 1 && c->sE && s < nstage - 1) {
+        hipEvent_t e;
+        HIPCK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->pipe_ev.push_back(e);
+        HIPCK(c, hipEventRecord(e, c->sC));
+        HIPCK(c, hipStreamWaitEvent(c->sE, e, 0));
+      }
     }
   }
   if (lead < nstage - 1) {  // join: c->st continues (cost kernel, copies) after the follower stages
+    hipStream_t lasts = (c->sE && lead + 1 < nstage - 1) ? c->sE : c->sC;
     HIPCK(c, hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
     c->pipe_ev.push_back(ev_join);
-    HIPCK(c, hipEventRecord(ev_join, c->sC));
+    HIPCK(c, hipEventRecord(ev_join, lasts));
     HIPCK(c, hipStreamWaitEvent(c->st, ev_join, 0));
   }
   return 0;
