@@ -13,6 +13,7 @@
 #include <cstring>
 #include <cstdlib>
 #include <map>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -42,6 +43,7 @@ struct sacopt_ctx {
   hipStream_t sA = nullptr, sB = nullptr;  // final-pass pipeline: dominant LMS stage / everything else
   hipStream_t sC = nullptr;                // follower stages of the optimizer rounds
   hipStream_t sE = nullptr;                // optimizer followers behind the first one (may be NULL: all on sC)
+  hipStream_t up = nullptr;                // stream of upload() (NULL: st); the full-frame pipeline stages its job tables on sB
   hipStream_t sAall = nullptr;             // lead stage of the full-frame pass when it has more workgroups than sA's reserved CUs
   hipStream_t sD = nullptr;                // final-pass pipeline: stages behind the second LMS stage (may be NULL)
   std::vector<hipEvent_t> pipe_ev;         // events of the last call's pipeline
@@ -326,7 +328,7 @@ template <class T>
 static int upload(sacopt_ctx *c, const std::vector<T> &h, T **d) {
   *d = arena_alloc<T>(c, h.size() ? h.size() : 1);
   if (!*d) { c->err = "device arena exhausted"; return 1; }
-  if (h.size()) HIPCK(c, hipMemcpyAsync(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, c->st));
+  if (h.size()) HIPCK(c, hipMemcpyAsync(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, c->up ? c->up : c->st));
   return 0;
 }
 template <class T>
@@ -487,7 +489,8 @@ static int eval_chains(sacopt_ctx *c, const ProfDesc &pd, const std::vector<DevF
       }
       LpcJob *dj = arena_alloc<LpcJob>(c, jobs.size());
       if (!dj) { c->err = "device arena exhausted"; return 1; }
-      const size_t mark = c->used;  // scratch is released once the stage has been enqueued (stream order)
+      // (the scratch is NOT handed back to the arena: memory reused "in stream order" is only safe for consumers on this
+      // stream, and the full-frame pipeline, enqueued next on other streams, would have overwritten it -- a fault seen once)
       int max_n = 0;
       for (LpcJob &j : jobs) {
         if (lpc_scratch_alloc(c, pd.type, j)) return 1;
@@ -497,7 +500,6 @@ static int eval_chains(sacopt_ctx *c, const ProfDesc &pd, const std::vector<DevF
       HIPCK(c, hipMemcpyAsync(dj, jobs.data(), jobs.size() * sizeof(LpcJob), hipMemcpyHostToDevice, c->st));
       HIPCK(c, hipStreamSynchronize(c->st));  // jobs vector is host-local
       if (sacopt_launch_lpc2(dj, (int)jobs.size(), max_n, c->st)) { c->err = "LPC2 launch failed"; return 1; }
-      c->used = mark;
     } else if (s == 0) {
       std::vector<LpcJob> jobs;
       for (int ci : todo) {
@@ -512,7 +514,6 @@ static int eval_chains(sacopt_ctx *c, const ProfDesc &pd, const std::vector<DevF
       }
       LpcJob *dj = arena_alloc<LpcJob>(c, jobs.size());
       if (!dj) { c->err = "device arena exhausted"; return 1; }
-      const size_t mark = c->used;
       int max_n = 0;
       for (LpcJob &j : jobs) {
         if (lpc_scratch_alloc(c, pd.type, j)) return 1;
@@ -521,7 +522,6 @@ static int eval_chains(sacopt_ctx *c, const ProfDesc &pd, const std::vector<DevF
       HIPCK(c, hipMemcpyAsync(dj, jobs.data(), jobs.size() * sizeof(LpcJob), hipMemcpyHostToDevice, c->st));
       HIPCK(c, hipStreamSynchronize(c->st));
       if (sacopt_launch_lpc3(dj, (int)jobs.size(), max_n, c->st)) { c->err = "LPC3 launch failed"; return 1; }
-      c->used = mark;
     } else {
       todo_s[s] = todo;  // LMS stages and the mixer are launched below, pipelined over chunks
     }
@@ -668,8 +668,16 @@ static int eval_chains(sacopt_ctx *c, const ProfDesc &pd, const std::vector<DevF
 // dominant stage alone. Everything is enqueued without host synchronisation, so a caller can
 // overlap it with work on c->st (the optimizer rounds). Results are identical to eval_chains.
 // `done` receives an event recorded when the last stage has finished.
+// `staged` (optional): event behind which the input samples are on the device. With it the pass does not touch c->st at
+// all -- its job tables go up on c->sB -- so it can be enqueued AFTER work that already sits on c->st (the optimizer's
+// first round) without waiting for it.
 static int final_pass_enqueue(sacopt_ctx *c, const ProfDesc &pd, const std::vector<DevFrame> &fr, std::vector<Chain> &chains,
-                              hipEvent_t *done) {
+                              hipEvent_t *done, hipEvent_t staged = nullptr) {
+  struct UpGuard { sacopt_ctx *c; ~UpGuard() { c->up = nullptr; } } up_guard{c};
+  if (staged) {
+    HIPCK(c, hipStreamWaitEvent(c->sB, staged, 0));
+    c->up = c->sB;
+  }
   const int nstage = pd.nlms + 2, last = pd.nlms + 1;
   const int nch = (int)chains.size();
   int max_n = 0;
@@ -820,8 +828,9 @@ static int final_pass_enqueue(sacopt_ctx *c, const ProfDesc &pd, const std::vect
   hipStream_t sLead = (c->sAall && lead_wgs > 32) ? c->sAall : c->sA;
   hipEvent_t ev_in;
   if (new_event(&ev_in)) return 1;
-  HIPCK(c, hipEventRecord(ev_in, c->st));  // inputs + job tables were staged on c->st
-  HIPCK(c, hipStreamWaitEvent(c->sB, ev_in, 0));
+  HIPCK(c, hipEventRecord(ev_in, staged ? c->sB : c->st));  // inputs + job tables are on the device behind this
+  c->up = nullptr;
+  if (!staged) HIPCK(c, hipStreamWaitEvent(c->sB, ev_in, 0));
   HIPCK(c, hipStreamWaitEvent(sLead, ev_in, 0));
   // The LPC stage runs on sB two chunks ahead of the lead stage (it is ~10x cheaper), so only its first
   // chunk is ever in front of the lead stage
@@ -877,16 +886,19 @@ static int final_pass_enqueue(sacopt_ctx *c, const ProfDesc &pd, const std::vect
 }
 
 // Full-frame (or any window) pass for all chains; long windows go through the pipeline.
-static int run_final_pass(sacopt_ctx *c, const ProfDesc &pd, const std::vector<DevFrame> &fr, std::vector<Chain> &chains,
-                          hipEvent_t *done) {
-  *done = nullptr;
+static bool final_pass_pipelined(const ProfDesc &pd, const std::vector<DevFrame> &fr, const std::vector<Chain> &chains) {
   int max_n = 0;
   for (const Chain &ch : chains) max_n = fr[ch.frame].n > max_n ? fr[ch.frame].n : max_n;
-  if (pd.type == SACOPT_PROFILE_FAST || max_n <= 2 * PIPE_CHUNK) {
+  return !(pd.type == SACOPT_PROFILE_FAST || max_n <= 2 * PIPE_CHUNK);
+}
+static int run_final_pass(sacopt_ctx *c, const ProfDesc &pd, const std::vector<DevFrame> &fr, std::vector<Chain> &chains,
+                          hipEvent_t *done, hipEvent_t staged = nullptr) {
+  *done = nullptr;
+  if (!final_pass_pipelined(pd, fr, chains)) {
     Memo memo;
     return eval_chains(c, pd, fr, chains, memo);
   }
-  return final_pass_enqueue(c, pd, fr, chains, done);
+  return final_pass_enqueue(c, pd, fr, chains, done, staged);
 }
 
 // Stage input frames: device pointers are used in place, host pointers are copied into the arena.
@@ -1122,8 +1134,10 @@ static size_t optimize_bytes(const ProfDesc &pd, int ncoef_loop, const std::vect
 }
 
 // The search itself, on frames already staged (fr[f].from/n = optimisation window), all on c->st.
+// `after_first` (optional) runs once, right after the first round's kernels are enqueued and before the host waits for them.
 static int optimize_core(sacopt_ctx *c, const ProfDesc &pd, const std::vector<DevFrame> &fr, const double *prof, int ncoef_loop,
-                         const std::vector<std::vector<double>> &grid, double *best, double *trace, int max_rows, int32_t *rows_out) {
+                         const std::vector<std::vector<double>> &grid, double *best, double *trace, int max_rows, int32_t *rows_out,
+                         const std::function<int()> &after_first = nullptr) {
   const int nframes = (int)fr.size();
   std::vector<double> st(nframes, 0.);  // one CostGolomb instance per Optimize call (codec.cpp:364)
   double *d_state;
@@ -1159,6 +1173,7 @@ static int optimize_core(sacopt_ctx *c, const ProfDesc &pd, const std::vector<De
         if (k >= nb) ch.coefs[i] = grid[i][k - nb];
       }
     if (eval_chains(c, pd, fr, chains, memo)) return 1;
+    if (!base_done && after_first && after_first()) return 1;
     std::vector<double> costs;
     if (cost_round(c, pd, fr, chains, tot, d_state, costs)) return 1;
     for (int f = 0; f < nframes; f++) {
@@ -1250,11 +1265,24 @@ extern "C" int sacopt_encode_frames(sacopt_ctx *c, int profile, int nframes, con
     for (int i = 0; i < pd.ncoef; i++) chains[f].coefs[i] = prof[3 * i + 2];
   }
   hipEvent_t done = nullptr;
-  if (run_final_pass(c, pd, fr, chains, &done)) return 1;
+  // The optimizer is the longer of the two and its first round needs ~20 ms of LPC work before its lead stage starts,
+  // the full-frame pipeline ~15 ms of host time to enqueue: the optimizer's first round goes first, the pipeline is
+  // enqueued while it runs (it stays off c->st: see final_pass_enqueue).
+  const bool opt_first = ncoef_loop > 0 && final_pass_pipelined(pd, fr, chains);
+  hipEvent_t staged = nullptr;
+  if (opt_first) {
+    HIPCK(c, hipEventCreateWithFlags(&staged, hipEventDisableTiming));
+    c->pipe_ev.push_back(staged);
+    HIPCK(c, hipEventRecord(staged, c->st));
+  } else if (run_final_pass(c, pd, fr, chains, &done)) return 1;
   if (ncoef_loop > 0) {  // Optimize on the centre window (codec.cpp:356-359)
     std::vector<DevFrame> win = fr;
     for (DevFrame &w : win) { w.n = w.numsamples / 8; w.from = (w.numsamples - w.n) / 2; }
-    if (optimize_core(c, pd, win, prof, ncoef_loop, grid, best, nullptr, 0, nullptr)) return 1;
+    bool ran = false;
+    auto enqueue_final = [&]() -> int { ran = true; return run_final_pass(c, pd, fr, chains, &done, staged); };
+    if (optimize_core(c, pd, win, prof, ncoef_loop, grid, best, nullptr, 0, nullptr,
+                      opt_first ? std::function<int()>(enqueue_final) : std::function<int()>())) return 1;
+    if (opt_first && !ran && run_final_pass(c, pd, fr, chains, &done, staged)) return 1;  // no round ran (empty grids)
   }
   if (done) HIPCK(c, hipStreamWaitEvent(c->st, done, 0));
   return emit_outputs(c, pd, fr, chains, out);
