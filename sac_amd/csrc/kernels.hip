@@ -640,6 +640,12 @@ __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs
   }
   const int lane = tid & 63, wave = tid >> 6;
   long long rounds = 0;
+#ifdef L1_PROF  // phase clocks of every wave (tools/l1_phases.py): products | P1 | walk + verification | update, until its barrier
+  long long pf[4] = {0, 0, 0, 0}, pfT = clock64();
+#define L1_TICK(i) { const long long now_ = clock64(); pf[i] += now_ - pfT; pfT = now_; }
+#else
+#define L1_TICK(i)
+#endif
 
   auto flush = [&](int tb, int te) {  // p and val[k+1] = x - p (CalcError, profile.cpp:141-148) for times [tb, te)
     for (int k = tid; k < CH; k += NT) {
@@ -686,6 +692,7 @@ __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs
       part += __hiloint2double(hi, lo);
     }
     if (hl == HW - 1 && valid[0]) sA[seg] = part;
+    L1_TICK(0)
     __syncthreads();
     // ---- pred = 0.; for i: pred += w[i]*hist[i]  -- strict order (spec_exact_sum: waves 0..3 sum candidates, wave 0 verifies)
     const double res = spec_exact_sum<NSEG, SEG / 4, SEGP>((uint32_t)(uintptr_t)&prods[0], sJ, &sX1, sA, wave < 4 ? wave : -1, wave == 0, dbg, rounds, lane);
@@ -693,7 +700,9 @@ __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs
       predv = res;
       pbuf[t & (CH - 1)] = res;
     }
+    L1_TICK(1)
     __syncthreads();
+    L1_TICK(2)
     // ---- Update (nlms.h:114-129)
     const double err = ringo[t & MO] - predv;
 #pragma unroll
@@ -704,8 +713,13 @@ __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs
         w[r] += (mu[r] * grad * rsq_emul2(eg[r] + 0.001, tab, bits));
       }
     }
+    L1_TICK(3)
   }
   if (tend > t0) flush((tend - 1) & ~(CH - 1), tend);
+#ifdef L1_PROF
+  __syncthreads();
+  if (lane == 0 && tend - t0 >= 64) { for (int i = 0; i < 4; i++) pout[t0 + 4 * wave + i] = (double)pf[i]; }
+#endif
   if (dbg & 128) {  // DEBUG: number of P2 passes
     __syncthreads();
     if (tid == 0) pout[t0] = (double)rounds;
