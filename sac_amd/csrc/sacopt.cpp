@@ -43,6 +43,7 @@ struct sacopt_ctx {
   hipStream_t sA = nullptr, sB = nullptr;  // final-pass pipeline: dominant LMS stage / everything else
   hipStream_t sC = nullptr;                // follower stages of the optimizer rounds
   hipStream_t sE = nullptr;                // optimizer followers behind the first one (may be NULL: all on sC)
+  hipStream_t split[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // alternative {st, sB, sC, sD, sE} (see sacopt_create)
   hipStream_t up = nullptr;                // stream of upload() (NULL: st); the full-frame pipeline stages its job tables on sB
   hipStream_t sAall = nullptr;             // lead stage of the full-frame pass when it has more workgroups than sA's reserved CUs
   hipStream_t sD = nullptr;                // final-pass pipeline: stages behind the second LMS stage (may be NULL)
@@ -232,6 +233,25 @@ extern "C" int sacopt_create(int device, const float *rsqrt_tab, int rsqrt_bits,
                hipExtStreamCreateWithCUMask(&c->sC, words, mr.data()) == hipSuccess &&
                hipExtStreamCreateWithCUMask(&c->sD, words, mr.data()) == hipSuccess &&
                hipExtStreamCreateWithCUMask(&c->sE, words, mr.data()) == hipSuccess;
+      // Second set for small batches of sacopt_encode_frames (split[]: st, sB, sC, sD, sE): the full-frame pass's follower
+      // streams on 32 CUs of their own, the optimizer on the remaining 192. An optimizer round's lead launch is as slow
+      // as its slowest workgroup, and the workgroups that shared a CU with a full-frame follower (busy all the time) were:
+      // encode 554 -> 537 ms for 15 frames. With more lead workgroups than 192 CUs (or a chip that is full anyway) the
+      // shared set is better (75 frames: 6.6 against 6.1 M samples/s).
+      if (masked && prop.multiProcessorCount >= 256) {
+        std::vector<uint32_t> mo(mr), mf(mr);
+        for (int cu = 32; cu < prop.multiProcessorCount; cu++) {
+          if (cu < 64) mo[cu >> 5] &= ~(1u << (cu & 31));
+          else mf[cu >> 5] &= ~(1u << (cu & 31));
+        }
+        const uint32_t *mk[5] = {mo.data(), mf.data(), mo.data(), mf.data(), mo.data()};
+        bool ok = true;
+        for (int i = 0; i < 5 && ok; i++) ok = hipExtStreamCreateWithCUMask(&c->split[i], words, mk[i]) == hipSuccess;
+        if (!ok) {
+          (void)hipGetLastError();
+          for (hipStream_t &p : c->split) if (p) { (void)hipStreamDestroy(p); p = nullptr; }
+        }
+      }
       if (masked) {
         std::vector<uint32_t> mall(mr);
         mall[0] = 0xffffffffu;
@@ -288,6 +308,7 @@ extern "C" void sacopt_destroy(sacopt_ctx *c) {
   if (c->sD) (void)hipStreamDestroy(c->sD);
   if (c->sAall) (void)hipStreamDestroy(c->sAall);
   if (c->sE) (void)hipStreamDestroy(c->sE);
+  for (hipStream_t p : c->split) if (p) (void)hipStreamDestroy(p);
   if (c->st) (void)hipStreamDestroy(c->st);
   delete c;
 }
@@ -344,7 +365,7 @@ static int begin_call(sacopt_ctx *c) {
   HIPCK(c, hipSetDevice(c->device));
   c->err.clear();
   // a call that failed half-way may have left work in flight on the pipeline streams; the arena is about to be reused
-  for (hipStream_t s : {c->st, c->sA, c->sAall, c->sB, c->sC, c->sD, c->sE})
+  for (hipStream_t s : {c->st, c->sA, c->sAall, c->sB, c->sC, c->sD, c->sE, c->split[0], c->split[1], c->split[2], c->split[3], c->split[4]})
     if (s) HIPCK(c, hipStreamSynchronize(s));
   for (auto &p : c->lms_ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   c->lms_ev.clear();
@@ -438,6 +459,18 @@ static size_t pipe_bytes(int n) {
   const size_t nchunk = (size_t)n / PIPE_CHUNK + 20;  // + the short first chunk and the halving tail
   return nchunk * (4 * (sizeof(LmsJob) + 256) + sizeof(MixJob) + 256 + sizeof(LpcJob) + 256) + 16 * 1024 * 8 + 16384;
 }
+
+// Job tables collected on the host and sent up in ONE copy (a copy per table cost ~70 us each: 150 of them put 10 ms in
+// front of the pipeline's first kernel).
+struct Stager {
+  std::vector<char> host;
+  size_t add(const void *p, size_t bytes) {
+    const size_t off = (host.size() + 255) & ~(size_t)255;
+    host.resize(off + bytes);
+    if (bytes) memcpy(host.data() + off, p, bytes);
+    return off;
+  }
+};
 
 // Run all chains through the cascade, re-using memoised stage outputs. `want_u`: also write s2u.
 static int eval_chains(sacopt_ctx *c, const ProfDesc &pd, const std::vector<DevFrame> &fr, std::vector<Chain> &chains,
@@ -550,12 +583,16 @@ static int eval_chains(sacopt_ctx *c, const ProfDesc &pd, const std::vector<DevF
       }
     }
   hipEvent_t ev_join = nullptr;
+  // ---- job tables of every stage and chunk: built first, one upload on c->st (a copy per table and chunk sat between the
+  // lead stage's launches: ~0.1 ms per chunk on the round's critical path)
+  Stager stg;
+  std::vector<std::vector<size_t>> o_jobs(nchunk, std::vector<size_t>(nstage, 0));
+  std::vector<std::vector<int>> n_jobs_all(nchunk, std::vector<int>(nstage, 0));
+  std::vector<long long> units_all(nchunk, 0);
   for (int k = 0; k < nchunk; k++) {
     const int t0 = k * chunk;
-    // ---- job tables of every stage for this chunk, staged on c->st ahead of the launches
-    std::vector<void *> d_jobs(nstage, nullptr);
-    std::vector<int> n_jobs(nstage, 0);
-    long long units = 0;
+    std::vector<int> &n_jobs = n_jobs_all[k];
+    long long &units = units_all[k];
     for (int s = lead; s < nstage; s++) {
       if (s <= pd.nlms) {
         const StageDesc &sd = pd.lms[s - 1];
@@ -575,9 +612,7 @@ static int eval_chains(sacopt_ctx *c, const ProfDesc &pd, const std::vector<DevF
           if (s == 1) units += j.n;
         }
         n_jobs[s] = (int)jobs.size();
-        LmsJob *dj = nullptr;
-        if (!jobs.empty() && upload(c, jobs, &dj)) return 1;
-        d_jobs[s] = dj;
+        o_jobs[k][s] = stg.add(jobs.data(), jobs.size() * sizeof(LmsJob));
       } else {
         std::vector<MixJob> jobs;
         for (size_t q = 0; q < todo_s[s].size(); q++) {
@@ -602,11 +637,18 @@ static int eval_chains(sacopt_ctx *c, const ProfDesc &pd, const std::vector<DevF
           jobs.push_back(j);
         }
         n_jobs[s] = (int)jobs.size();
-        MixJob *dj = nullptr;
-        if (!jobs.empty() && upload(c, jobs, &dj)) return 1;
-        d_jobs[s] = dj;
+        o_jobs[k][s] = stg.add(jobs.data(), jobs.size() * sizeof(MixJob));
       }
     }
+  }
+  char *d_tables = arena_alloc<char>(c, stg.host.size() + 256);
+  if (!d_tables) { c->err = "device arena exhausted"; return 1; }
+  HIPCK(c, hipMemcpyAsync(d_tables, stg.host.data(), stg.host.size(), hipMemcpyHostToDevice, c->st));
+  for (int k = 0; k < nchunk; k++) {
+    std::vector<void *> d_jobs(nstage, nullptr);
+    for (int s = lead; s < nstage; s++) d_jobs[s] = d_tables + o_jobs[k][s];
+    const std::vector<int> &n_jobs = n_jobs_all[k];
+    const long long units = units_all[k];
     // ---- launches: lead stage on c->st, the first follower on c->sC, the others on c->sE, each behind an event: three
     // pipeline stages per chunk (one follower stream ran (32,16), (8,4) and the mixer of a chunk back to back, as long as
     // an lms2 lead chunk: the followers fell behind and left a tail of three chunks after the lead's last one)
@@ -738,7 +780,10 @@ static int final_pass_enqueue(sacopt_ctx *c, const ProfDesc &pd, const std::vect
       if (!j.cstate[k] || !j.estate[k]) { c->err = "device arena exhausted"; return 1; }
     }
   }
+  Stager stg;
   std::vector<LpcJob *> d_lpc(nchunk, nullptr);
+  std::vector<size_t> o_lpc(nchunk, 0), o_mix(nchunk, 0);
+  std::vector<std::vector<size_t>> o_lms(pd.nlms, std::vector<size_t>(nchunk, 0));
   std::vector<int> n_lpc(nchunk, 0), len_lpc(nchunk, 0);
   for (int k = 0; k < nchunk; k++) {
     const int t0 = edges[k];
@@ -754,7 +799,7 @@ static int final_pass_enqueue(sacopt_ctx *c, const ProfDesc &pd, const std::vect
       jobs.push_back(j);
     }
     n_lpc[k] = (int)jobs.size();
-    if (!jobs.empty() && upload(c, jobs, &d_lpc[k])) return 1;
+    o_lpc[k] = stg.add(jobs.data(), jobs.size() * sizeof(LpcJob));
   }
   std::vector<std::vector<LmsJob *>> d_lms(pd.nlms, std::vector<LmsJob *>(nchunk, nullptr));
   std::vector<std::vector<int>> n_lms(pd.nlms, std::vector<int>(nchunk, 0));
@@ -790,7 +835,7 @@ static int final_pass_enqueue(sacopt_ctx *c, const ProfDesc &pd, const std::vect
         if (q == 0) units[k] += j.n;
       }
       n_lms[q][k] = (int)jobs.size();
-      if (!jobs.empty() && upload(c, jobs, &d_lms[q][k])) return 1;
+      o_lms[q][k] = stg.add(jobs.data(), jobs.size() * sizeof(LmsJob));
     }
     std::vector<MixJob> jobs;
     for (int i = 0; i < nch; i++) {
@@ -815,7 +860,17 @@ static int final_pass_enqueue(sacopt_ctx *c, const ProfDesc &pd, const std::vect
       jobs.push_back(j);
     }
     n_mix[k] = (int)jobs.size();
-    if (!jobs.empty() && upload(c, jobs, &d_mix[k])) return 1;
+    o_mix[k] = stg.add(jobs.data(), jobs.size() * sizeof(MixJob));
+  }
+  {
+    char *dev = arena_alloc<char>(c, stg.host.size() + 256);
+    if (!dev) { c->err = "device arena exhausted"; return 1; }
+    HIPCK(c, hipMemcpyAsync(dev, stg.host.data(), stg.host.size(), hipMemcpyHostToDevice, c->up ? c->up : c->st));
+    for (int k = 0; k < nchunk; k++) {
+      d_lpc[k] = reinterpret_cast<LpcJob *>(dev + o_lpc[k]);
+      d_mix[k] = reinterpret_cast<MixJob *>(dev + o_mix[k]);
+      for (int q = 0; q < pd.nlms; q++) d_lms[q][k] = reinterpret_cast<LmsJob *>(dev + o_lms[q][k]);
+    }
   }
   // ---- enqueue
   auto new_event = [&](hipEvent_t *e) -> int {
@@ -1255,6 +1310,15 @@ extern "C" int sacopt_encode_frames(sacopt_ctx *c, int profile, int nframes, con
     if (ncoef_loop > 0) need += optimize_bytes(pd, ncoef_loop, grid, total_cand, ns / 8);
   }
   if (arena_reserve(c, need)) return 1;
+  // small batches: the stream set that keeps the full-frame followers off the optimizer's CUs (see sacopt_create)
+  struct SetGuard {
+    sacopt_ctx *c; hipStream_t keep[5]; bool on;
+    ~SetGuard() { if (on) { c->st = keep[0]; c->sB = keep[1]; c->sC = keep[2]; c->sD = keep[3]; c->sE = keep[4]; } }
+  } set_guard{c, {c->st, c->sB, c->sC, c->sD, c->sE}, false};
+  if (c->split[0] && ncoef_loop > 0 && nframes <= 16 && pd.type == SACOPT_PROFILE_HIGH && !getenv("SACOPT_NOSPLIT")) {
+    set_guard.on = true;
+    c->st = c->split[0]; c->sB = c->split[1]; c->sC = c->split[2]; c->sD = c->split[3]; c->sE = c->split[4];
+  }
   HIPCK(c, hipEventRecord(c->ev0, c->st));
   std::vector<DevFrame> fr;
   if (stage_frames(c, nframes, frames, nullptr, nullptr, fr)) return 1;
