@@ -37,6 +37,23 @@ __device__ __forceinline__ double rsq_emul(double a, const uint16_t *tab, int bi
   return (double)__uint_as_float(tb);
 }
 
+// rsq_emul with the integer part folded (argument is eg + 0.001 > 0 or NaN):
+//   index  = bits [23-bits, 23] of the float (top mantissa bits + exponent parity)
+//   rescale: table value * 2^-q, q = ((e+1)>>1) - 64
+__device__ __forceinline__ double rsq_emul2(double a, const uint16_t *tab, int bits) {
+  const uint32_t u = __float_as_uint((float)a);
+  const uint32_t off = (u >> (22 - bits)) & (((2u << bits) - 1u) << 1);  // byte offset of the 16-bit table entry
+  const uint32_t x = ((u + 0x800000u) >> 1) & 0x7f800000u;
+  uint32_t tb = RSQ_UNPACK(*reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(tab) + off)) + (0x20000000u - x);
+  // NaN stays NaN, +inf -> +0: rare, so one class test and a wave-uniform branch instead of seven selects per tap
+  if (__builtin_amdgcn_ballot_w64(__builtin_amdgcn_classf(__uint_as_float(u), 0x207)) != 0ull) {
+    asm volatile("" ::: "memory");  // keeps this a branch (the compiler turns it back into selects otherwise)
+    if ((u & 0x7f800000u) == 0x7f800000u) tb = (u & 0x7fffffu) ? (u | 0x400000u) : 0u;
+  }
+  return (double)__uint_as_float(tb);
+}
+
+
 // (int32_t)x as the reference's x86-64 build converts (cvttsd2si): anything outside int32, NaN included, becomes
 // INT32_MIN (the GPU's own conversion saturates). Only garbage residuals on the decoder side get there.
 __device__ __forceinline__ int32_t cvt_i32_x86(double x) {
@@ -498,7 +515,7 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
           const double err = cs[r] ? e1 : e0;
           const double grad = err * h[r];
           eg[r] = 0.95 * eg[r] + (1.0 - 0.95) * (grad * grad);
-          w[r] += (mu[r] * grad * rsq_emul(eg[r] + 0.001, tab, bits));
+          w[r] += (mu[r] * grad * rsq_emul2(eg[r] + 0.001, tab, bits));
         }
       }
       continue;
@@ -531,7 +548,7 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
         const double err = cs[r] ? e1 : e0;
         const double grad = err * h[r];
         eg[r] = 0.95 * eg[r] + (1.0 - 0.95) * (grad * grad);
-        w[r] += (mu[r] * grad * rsq_emul(eg[r] + 0.001, tab, bits));
+        w[r] += (mu[r] * grad * rsq_emul2(eg[r] + 0.001, tab, bits));
       }
     }
   }
@@ -566,19 +583,6 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
 #define L1_CH 256
 #define L1_RLO 2048
 #define L1_RLX 1024
-
-// rsq_emul with the integer part folded (argument is eg + 0.001 > 0 or NaN):
-//   index  = bits [23-bits, 23] of the float (top mantissa bits + exponent parity)
-//   rescale: table value * 2^-q, q = ((e+1)>>1) - 64
-__device__ __forceinline__ double rsq_emul2(double a, const uint16_t *tab, int bits) {
-  const uint32_t u = __float_as_uint((float)a);
-  const uint32_t idx = (u >> (23 - bits)) & ((2u << bits) - 1u);
-  const uint32_t x = ((u + 0x800000u) >> 1) & 0x7f800000u;
-  uint32_t tb = RSQ_UNPACK(tab[idx]) + (0x20000000u - x);
-  if ((u & 0x7f800000u) == 0x7f800000u) tb = (u & 0x7fffffu) ? (u | 0x400000u) : 0u;  // NaN stays NaN, +inf -> +0
-  return (double)__uint_as_float(tb);
-}
-
 
 __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs, const uint16_t *__restrict__ gtab, int bits) {
   constexpr int S = 1280, T = 1920, NT = L1_NT, R = L1_R, CH = L1_CH, MO = L1_RLO - 1, MX = L1_RLX - 1;
