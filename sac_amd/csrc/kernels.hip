@@ -614,7 +614,7 @@ __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs
   __syncthreads();
 
   double w[R], eg[R], mu[R];
-  const double *hb[R];
+  uint32_t hb[R];  // LDS byte address of the tap's history ring (a generic pointer here made every history read a flat load)
   int hoff[R], hmask[R], pa[R];
   bool valid[R];
   // carried state: same layout as k_lms<1280,640,...> (w at [tap], eg at [4096 + tap], tap = channel*1920 + i),
@@ -631,10 +631,10 @@ __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs
     const int i = SEG * seg + HW * r + hl;
     tap[r] = i;
     valid[r] = seg < NSEG;
-    if (i < S) { hb[r] = ringo; hmask[r] = MO; hoff[r] = (-(1 + i)) & MO; mu[r] = job.mu1; }
-    else { hb[r] = ringx; hmask[r] = MX; hoff[r] = (-(lagx + (i - S))) & MX; mu[r] = job.mu2; }
+    if (i < S) { hb[r] = (uint32_t)(uintptr_t)ringo; hmask[r] = MO; hoff[r] = (-(1 + i)) & MO; mu[r] = job.mu1; }
+    else { hb[r] = (uint32_t)(uintptr_t)ringx; hmask[r] = MX; hoff[r] = (-(lagx + (i - S))) & MX; mu[r] = job.mu2; }
     pa[r] = seg * SEGP + HW * r + hl;
-    if (!valid[r]) { hb[r] = ringo; hmask[r] = MO; hoff[r] = 0; pa[r] = 0; }
+    if (!valid[r]) { hb[r] = (uint32_t)(uintptr_t)ringo; hmask[r] = MO; hoff[r] = 0; pa[r] = 0; }
     w[r] = 0.; eg[r] = 0.;
     if (t0 > 0 && st && valid[r]) { w[r] = st[i]; eg[r] = st[4096 + i]; }
   }
@@ -675,8 +675,10 @@ __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs
     // ---- products w[i]*hist[i] (nlms.h:111)
     double h[R], part = 0.;
 #pragma unroll
+    for (int r = 0; r < R; r++)  // all history reads first: behind a product store the compiler would not move them
+      h[r] = *(const __attribute__((address_space(3))) double *)(uintptr_t)(hb[r] + 8u * (uint32_t)((t + hoff[r]) & hmask[r]));
+#pragma unroll
     for (int r = 0; r < R; r++) {
-      h[r] = hb[r][(t + hoff[r]) & hmask[r]];
       const double pr = w[r] * h[r];
       if (valid[r]) prods[pa[r]] = pr;
       part += pr;
