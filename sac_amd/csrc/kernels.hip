@@ -418,8 +418,9 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
     // ---- products w[i]*hist[i] (nlms.h:111)
     double h[R], part[2] = {0., 0.};
 #pragma unroll
+    for (int r = 0; r < R; r++) h[r] = ring[hsel[r]][(t + hoff[r]) & M];  // all reads first (not moved across the product stores otherwise)
+#pragma unroll
     for (int r = 0; r < R; r++) {
-      h[r] = ring[hsel[r]][(t + hoff[r]) & M];
       const double pr = w[r] * h[r];
       if (valid[r]) (&prods[0][0])[paddr[r]] = pr;
       if (SPEC) part[BOTH ? (r >> 2) : 0] += pr;
