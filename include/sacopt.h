@@ -24,6 +24,11 @@ typedef struct sacopt_ctx sacopt_ctx;
 #define SACOPT_PROFILE_FAST   0 /* StereoFast   src/profile.cpp:3-43   (1 coef)  */
 #define SACOPT_PROFILE_NORMAL 1 /* StereoNormal src/profile.cpp:46-111 (6 coefs) */
 #define SACOPT_PROFILE_HIGH   2 /* StereoHigh   src/profile.cpp:113-186 (8 coefs) */
+/* StereoHigh with a 32-tap OLS stage, LPC3(alpha, S = 24, D = 8, k = 8, regp = 500): BASELINE configs[4] ("32-tap OLS + long
+ * LMS cascade"). Same 8 coefficients and tables as HIGH. The reference's LPC3 takes S and D as constructor arguments
+ * (src/pred/lpc.h:181-185) but no profile it ships uses 24 + 8 (src/profile.cpp:116), so the stage is pinned against the
+ * reference class and the cascade against the oracle only. Encoder side only (predict / get_costs / optimize / encode). */
+#define SACOPT_PROFILE_HIGH32 3
 #define SACOPT_MAX_COEFS 8
 
 /* One frame of one stereo pair (FrameCoder::samples[0..1], src/codec.h:29). */
@@ -84,6 +89,13 @@ int sacopt_get_costs(sacopt_ctx *ctx, int profile, int nframes, const sacopt_fra
                      const int32_t *from, const int32_t *n, int ncand, const double *cand_coefs,
                      double *costs, double *cost_state);
 
+/* The candidates of the LAST sacopt_get_costs call on this context, costed again -- CostGolomb::Calc over the same
+ * residuals in the same order (src/codec.cpp:349-350) -- from another running-mean start state cost_state[f] (in/out;
+ * NULL = 0). The cascade is not re-run and the residuals do not leave the device. Any other call on the context discards
+ * the residuals (then this fails). Used by the multi-GPU candidate split, where a rank's slice of the
+ * grid is first costed from a guessed state and then from the state the previous slice really ended with. */
+int sacopt_recost_last(sacopt_ctx *ctx, double *costs, double *cost_state);
+
 /* ---- FrameCoder::Optimize  src/codec.cpp:354-408 --------------------------------------------- */
 /* Coordinate grid search over the first `ncoef_loop` coefficients (the reference hard-codes 8,
  * codec.cpp:389; pass the profile's coefficient count for fast/normal). prof = ncoef x
@@ -118,8 +130,8 @@ typedef struct {
 } sacopt_dec_frame;
 /* coefs: nframes x ncoef predictor parameters (NULL = base profile, what DecodeFile uses, src/codec.cpp:463-478).
  * Fresh predictor state per frame; frames are decoded concurrently, one workgroup each. A mapped residual that asks
- * for more used values than the table holds (no encoder writes one; the reference would not terminate) decodes as
- * a step of +-131073. */
+ * for more used values than the table holds in its direction (no encoder writes one; the reference would not terminate)
+ * decodes as a step of +-131073; every other case, predictions far outside the table included, gives the reference's value. */
 int sacopt_unpredict_stereo_frames(sacopt_ctx *ctx, int profile, int nframes, const sacopt_dec_frame *frames,
                                    const double *coefs);
 
@@ -132,8 +144,8 @@ int sacopt_cost_meanrms(sacopt_ctx *ctx, const int32_t *buf, int n, double *cost
  * Supported (S,D): (1280,640) (256,128) (32,16) (8,4). x/p are host or device doubles. */
 int sacopt_lms_pair(sacopt_ctx *ctx, int S, int D, double mu1, double mu2, const double *x0,
                     const double *x1, int n, double *p0, double *p1);
-/* Stereo pair of LPC3(alpha,16,8,8,500) (src/pred/lpc.h:172-228). */
-int sacopt_lpc3_pair(sacopt_ctx *ctx, double alpha, const int32_t *s0, const int32_t *s1, int n,
+/* Stereo pair of LPC3(alpha,S,D,8,500) (src/pred/lpc.h:172-228). Built (S,D): (16,8) as shipped, (24,8). */
+int sacopt_lpc3_pair(sacopt_ctx *ctx, double alpha, int S, int D, const int32_t *s0, const int32_t *s1, int n,
                      double *p0, double *p1);
 /* RLS(nst,alpha) mixer (src/pred/rls.cpp:61-108): p[t] = Predict(pv[t][0..nst)); Update(val[t]). */
 int sacopt_rls_run(sacopt_ctx *ctx, int nst, double alpha, const double *pv, const double *val,

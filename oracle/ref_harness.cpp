@@ -251,10 +251,10 @@ void ref_lms_pair(int S, int D, double mu1, double mu2, const double *x0, const 
   }
 }
 
-// One stereo pair of LPC3(alpha,16,8,8,500) stages driven as StereoHigh/Normal drive them.
-void ref_lpc3_pair(double alpha, const int32_t *s0, const int32_t *s1, int n, double *p0, double *p1) {
+// One stereo pair of LPC3(alpha,S,D,8,500) stages (lpc.h:181: S, D are constructor arguments) driven as StereoHigh/Normal drive them.
+void ref_lpc3_pair(double alpha, int S, int D, const int32_t *s0, const int32_t *s1, int n, double *p0, double *p1) {
   CoutMute mute;
-  std::vector<LPC3> lpc(2, LPC3(alpha, 16, 8, 8, 500));
+  std::vector<LPC3> lpc(2, LPC3(alpha, S, D, 8, 500));
   double prev1 = 0.;
   for (int t = 0; t < n; t++) {
     p0[t] = lpc[0].Predict(prev1);
@@ -337,5 +337,58 @@ int ref_encode_residuals(int profile, const int32_t *s0, const int32_t *s1, int 
   fc.framestats[0].maxbpn_map = maxbpn[2]; fc.framestats[1].maxbpn_map = maxbpn[3];
   fc.Encode();
   return pack_frame(fc, out, cap);
+}
+
+// Encode() alone, channel by channel: the BitplaneCoder payloads a host-side container writer (sac_amd/host/sacfile.h)
+// packs. out = payload0 | payload1; info = {len0, enc_mapped0, flagbits0, len1, enc_mapped1, flagbits1} with flagbits =
+// maxbpn_map when mapped, else maxbpn (codec.cpp:492-497).
+int ref_encode_channels(int profile, const int32_t *s0, const int32_t *s1, int total, const int32_t *u0, const int32_t *u1,
+                        const int32_t *m0, const int32_t *m1, const int *maxbpn, uint8_t *out, int cap, int *info) {
+  CoutMute mute;
+  FrameCoder fc(2, total, profile);
+  load_frame(fc, s0, s1, total);
+  for (int i = 0; i < total; i++) {
+    fc.s2u_error[0][i] = u0[i]; fc.s2u_error[1][i] = u1[i];
+    fc.s2u_error_map[0][i] = m0[i]; fc.s2u_error_map[1][i] = m1[i];
+  }
+  fc.framestats[0].maxbpn = maxbpn[0]; fc.framestats[1].maxbpn = maxbpn[1];
+  fc.framestats[0].maxbpn_map = maxbpn[2]; fc.framestats[1].maxbpn_map = maxbpn[3];
+  fc.Encode();
+  int pos = 0;
+  for (int ch = 0; ch < 2; ch++) {
+    const int len = (int)fc.encoded[ch].GetBufPos();
+    if (pos + len > cap) return -1;
+    memcpy(out + pos, fc.encoded[ch].GetBuf().data(), len);
+    pos += len;
+    info[3 * ch] = len;
+    info[3 * ch + 1] = fc.framestats[ch].enc_mapped ? 1 : 0;
+    info[3 * ch + 2] = fc.framestats[ch].enc_mapped ? fc.framestats[ch].maxbpn_map : fc.framestats[ch].maxbpn;
+  }
+  return pos;
+}
+// Decode() alone (codec.cpp:282-300, :474-478): payloads as ReadEncoded leaves them -> error[ch][0..n) and, for a mapped
+// channel, the Remap tables the MapEncoder decoded (usedl[0..32768] then usedh[0..32768], one byte each).
+void ref_decode_channels(int profile, int n, const uint8_t *p0, int len0, int mapped0, int bpn0, const uint8_t *p1, int len1,
+                         int mapped1, int bpn1, int32_t *e0, int32_t *e1, unsigned char *used0, unsigned char *used1) {
+  CoutMute mute;
+  FrameCoder fc(2, n, profile);
+  fc.SetNumSamples(n);
+  const uint8_t *p[2] = {p0, p1};
+  const int len[2] = {len0, len1}, mapped[2] = {mapped0, mapped1}, bpn[2] = {bpn0, bpn1};
+  unsigned char *used[2] = {used0, used1};
+  for (int ch = 0; ch < 2; ch++) {
+    fc.framestats[ch].enc_mapped = mapped[ch] != 0;
+    fc.framestats[ch].maxbpn = bpn[ch];  // ReadEncoded: maxbpn = flag & 0xff for both kinds (codec.cpp:519)
+    std::vector<uint8_t> &b = fc.encoded[ch].GetBuf();
+    b.assign(p[ch], p[ch] + len[ch]);
+    b.resize(len[ch] + 64, 0);
+  }
+  fc.Decode();
+  for (int i = 0; i < n; i++) { e0[i] = fc.error[0][i]; e1[i] = fc.error[1][i]; }
+  for (int ch = 0; ch < 2; ch++)
+    if (mapped[ch] && used[ch]) {
+      const int sc = fc.framestats[ch].mymap.scale;
+      for (int i = 0; i <= sc; i++) { used[ch][i] = fc.framestats[ch].mymap.usedl[i]; used[ch][sc + 1 + i] = fc.framestats[ch].mymap.usedh[i]; }
+    }
 }
 }

@@ -412,7 +412,7 @@ int oracle_base_profile(int profile, double *out) {
   int n;
   if (profile == 0) { src = &fast[0][0]; n = 1; }
   else if (profile == 1) { src = &normal[0][0]; n = 6; }
-  else if (profile == 2) { src = &high[0][0]; n = 8; }
+  else if (profile == 2 || profile == 3) { src = &high[0][0]; n = 8; } /* 3: StereoHigh with LPC3(alpha,24,8,8,500) -- no reference counterpart */
   else return 0;
   for (int i = 0; i < 3 * n; i++) out[i] = src[i];
   return n;
@@ -447,10 +447,11 @@ static stereo_t *stereo_new(int type, const double *c) {
       lms_init(&s->lms[2][ch], 8, 4, c[4], c[4]);
       rls_init(&s->mix[ch], 3, c[5]);
     }
-  } else { /* StereoHigh, profile.cpp:113-124 */
+  } else { /* StereoHigh, profile.cpp:113-124; type 3: the same cascade with a 32-tap OLS stage (S = 24, D = 8), a shape the
+              reference's LPC3 constructor accepts (lpc.h:181) but no shipped profile uses: parity unpinned at cascade level */
     s->nlms = 4;
     for (int ch = 0; ch < 2; ch++) {
-      lpc3_init(&s->lpc[ch], c[0], 16, 8, 8, 500);
+      lpc3_init(&s->lpc[ch], c[0], type == 3 ? 24 : 16, 8, 8, 500);
       lms_init(&s->lms[0][ch], 1280, 640, c[1], c[2]);
       lms_init(&s->lms[1][ch], 256, 128, c[3], c[4]);
       lms_init(&s->lms[2][ch], 32, 16, c[5], c[5]);
@@ -608,14 +609,20 @@ static int32_t remap_unmap(const remap_t *r, int32_t pred, int32_t merr) { /* ma
   int sgn = 1;
   if (merr == 0) return 0;
   if (merr < 0) { merr = -merr; sgn = -1; }
-  int err = 1, terr = 0;
+  long long err = 1;
+  int terr = 0;
   while (1) {
-    if (remap_is_used(r, pred + (sgn * err))) terr++;
+    const long long v = (long long)pred + sgn * err;
+    /* past the far edge of the table nothing is used any more: the reference would loop forever (no encoder writes such a
+       stream); stop with a sentinel */
+    if (sgn > 0 ? v > RSCALE : v < -RSCALE) return sgn * (4 * RSCALE + 1);
+    /* before the near edge isUsed() is false as well: the reference walks there one step at a time; same result, skipped */
+    if (sgn > 0 ? v < -RSCALE : v > RSCALE) { err = sgn > 0 ? (-(long long)RSCALE - pred) : ((long long)pred - RSCALE); continue; }
+    if (remap_is_used(r, (int)v)) terr++;
     if (terr == merr) break;
-    if (err > 4 * RSCALE) break; /* the reference loops forever on a stream no encoder writes; stop */
     err++;
   }
-  return sgn * err;
+  return (int32_t)(sgn * err);
 }
 static int32_t clamp_i32(int32_t v, int32_t lo, int32_t hi) { return v < lo ? lo : v > hi ? hi : v; } /* global.h:16 */
 
@@ -634,12 +641,12 @@ static void stereo_unstep(stereo_t *s, int32_t e0, int32_t e1, const remap_t *ma
     s->x[1] = *v1;
   } else {
     int32_t p0 = (int32_t)round(cascade_predict(s, 0, 1));
-    if (s->type == 2) p0 = clamp_i32(p0, minval[0], maxval[0]);
+    if (s->type >= 2) p0 = clamp_i32(p0, minval[0], maxval[0]);
     if (map0) e0 = remap_unmap(map0, p0, e0);
     *v0 = e0 + p0;
     cascade_calc_error(s, 0, *v0);
     int32_t p1 = (int32_t)round(cascade_predict(s, 1, 0));
-    if (s->type == 2) p1 = clamp_i32(p1, minval[1], maxval[1]);
+    if (s->type >= 2) p1 = clamp_i32(p1, minval[1], maxval[1]);
     if (map1) e1 = remap_unmap(map1, p1, e1);
     *v1 = e1 + p1;
     cascade_calc_error(s, 1, *v1);
@@ -769,10 +776,10 @@ void oracle_lms_pair(int S, int D, double mu1, double mu2, const double *x0, con
   lms_free(&l[0]); lms_free(&l[1]);
 }
 
-void oracle_lpc3_pair(double alpha, const int32_t *s0, const int32_t *s1, int n, double *p0, double *p1) {
+void oracle_lpc3_pair(double alpha, int S, int D, const int32_t *s0, const int32_t *s1, int n, double *p0, double *p1) {
   lpc3_t *l = (lpc3_t *)malloc(2 * sizeof(lpc3_t));
-  lpc3_init(&l[0], alpha, 16, 8, 8, 500);
-  lpc3_init(&l[1], alpha, 16, 8, 8, 500);
+  lpc3_init(&l[0], alpha, S, D, 8, 500);
+  lpc3_init(&l[1], alpha, S, D, 8, 500);
   double prev1 = 0.;
   for (int t = 0; t < n; t++) {
     p0[t] = lpc3_predict(&l[0], prev1);
@@ -797,7 +804,7 @@ void oracle_cascade_trace(int profile, const double *coefs, const int32_t *s0, c
                           double *p_out, double *v_out, int32_t *e0, int32_t *e1) {
   double base[8 * 3], c[8];
   int nc = oracle_base_profile(profile, base);
-  if (profile != 1 && profile != 2) return;
+  if (profile < 1 || profile > 3) return;
   for (int i = 0; i < nc; i++) c[i] = coefs ? coefs[i] : base[3 * i + 2];
   stereo_t *sp = stereo_new(profile, c);
   const int nst = sp->nlms + 1;

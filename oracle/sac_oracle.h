@@ -49,7 +49,7 @@ int oracle_optimize(int profile, const double *prof, int ncoef_loop, const int32
 /* Stage-level entry points used to pin individual kernels. */
 void oracle_lms_pair(int S, int D, double mu1, double mu2, const double *x0, const double *x1,
                      int n, double *p0, double *p1);
-void oracle_lpc3_pair(double alpha, const int32_t *s0, const int32_t *s1, int n, double *p0,
+void oracle_lpc3_pair(double alpha, int S, int D, const int32_t *s0, const int32_t *s1, int n, double *p0,
                       double *p1);
 void oracle_rls_run(int n, double alpha, const double *pv, const double *val, int len, double *p);
 void oracle_cascade_trace(int profile, const double *coefs, const int32_t *s0, const int32_t *s1,

@@ -197,7 +197,7 @@ __device__ __forceinline__ int ulp_shift(int v, int ea, int eb) {  // offset in 
 // ------------------------------------------------------------------------------------------
 template <int NSEG, int STEPS, int SEGP>
 __device__ __forceinline__ double spec_exact_sum(uint32_t prods_addr, int (*sJ)[16], double *sX1, const double *sA, int group,
-                                                 bool walker, int dbg, long long &rounds, const int lane) {
+                                                 bool walker, int dbg, long long &rounds, const int lane, int *hist = nullptr) {
   constexpr int NB = NSEG - 1;  // last boundary = input of the last segment
   static_assert(STEPS == 32, "one pass = 32 MFMA steps");
   auto pass = [](uint32_t ad, double c0) { return mfma_pass32(ad, c0); };
@@ -272,6 +272,21 @@ __device__ __forceinline__ double spec_exact_sum(uint32_t prods_addr, int (*sJ)[
       const bool bad = (jD < NB) && (__double_as_longlong(res) != __double_as_longlong(xn));
       const unsigned long long mask = __ballot(bad);
       rounds++;
+#ifdef SACOPT_ABLATE
+      if (hist && mask == 0ull) {  // statistics (tools/ongrid.py): how far from the guess the exact boundary values lie
+        const bool inb = jA >= 1 && jA <= NB;
+        const double q = (x - gBase) * gIU;
+        const bool ongrid = !inb || (ex != 0 && q == (double)(long long)q && gBase + q * gU == x);
+        int dev = (inb && ongrid) ? abs((int)q - 8) : 0;
+        for (int o = 1; o < 16; o <<= 1) dev = max(dev, __shfl_xor(dev, o));
+        const bool allgrid = __ballot(!ongrid) == 0ull;
+        if (lane == 0) {
+          const int bin = !allgrid ? 7 : dev <= 7 ? 0 : dev <= 15 ? 1 : dev <= 23 ? 2 : dev <= 31 ? 3 : dev <= 63 ? 4 : dev <= 127 ? 5 : 6;
+          hist[bin]++;
+          if (guard > 0) hist[8]++;
+        }
+      }
+#endif
       if (mask == 0ull || (dbg & 16)) break;
       int f = 0;  // first failing segment (D-layout lane of chain j: 16*(j&3) + 4*(j>>2))
       while (f < NB && !((mask >> (16 * (f & 3) + 4 * (f >> 2))) & 1ull)) f++;
@@ -334,7 +349,11 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
 
   const LmsJob job = jobs[blockIdx.x];
   const int tid = threadIdx.x, t0 = job.t0, tend = job.t0 + job.n;
-  const int dbg = bits >> 8;  // A/B timing switches (tools/ablate.py): 2 = skip the update, 16 = single P2 pass
+#ifdef SACOPT_ABLATE
+  const int dbg = bits >> 8;  // A/B timing switches of tools/ builds (tools/ablate.py): 2 = skip the update, 16 = single P2 pass
+#else
+  constexpr int dbg = 0;      // the product library has no switch that changes a result
+#endif
   bits &= 0xff;
   for (int i = tid; i < (2 << bits); i += NT) tab[i] = gtab[i];
   for (int i = tid; i < 2 * RL; i += NT) (&ring[0][0])[i] = 0.;
@@ -597,6 +616,12 @@ __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs
   __shared__ double sX1;
   __shared__ double predv;
   __shared__ uint16_t tab[RSQ_LDS_MAX];
+#ifdef SACOPT_ABLATE
+  __shared__ int hist[16];
+  if (threadIdx.x < 16) hist[threadIdx.x] = 0;
+#else
+  int *const hist = nullptr;
+#endif
 
   const LmsJob job = jobs[blockIdx.x >> 1];
   const int c = blockIdx.x & 1;
@@ -606,7 +631,11 @@ __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs
   double *xnout = c ? job.xn[1] : job.xn[0];
   const int lagx = c ? 0 : 1;  // ch0: Predict(x1(t-1)); ch1: Predict(x0(t))  (profile.cpp:128-132)
   const int tid = threadIdx.x, t0 = job.t0, tend = job.t0 + job.n;
+#ifdef SACOPT_ABLATE
   const int dbg = bits >> 8;
+#else
+  constexpr int dbg = 0;
+#endif
   bits &= 0xff;
   for (int i = tid; i < (2 << bits); i += NT) tab[i] = gtab[i];
   for (int i = tid; i < L1_RLO; i += NT) ringo[i] = 0.;
@@ -702,7 +731,7 @@ __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs
     L1_TICK(0)
     __syncthreads();
     // ---- pred = 0.; for i: pred += w[i]*hist[i]  -- strict order (spec_exact_sum: waves 0..3 sum candidates, wave 0 verifies)
-    const double res = spec_exact_sum<NSEG, SEG / 4, SEGP>((uint32_t)(uintptr_t)&prods[0], sJ, &sX1, sA, wave < 4 ? wave : -1, wave == 0, dbg, rounds, lane);
+    const double res = spec_exact_sum<NSEG, SEG / 4, SEGP>((uint32_t)(uintptr_t)&prods[0], sJ, &sX1, sA, wave < 4 ? wave : -1, wave == 0, dbg, rounds, lane, hist);
     if (wave == 0 && lane == 16 * ((NSEG - 1) & 3) + 4 * ((NSEG - 1) >> 2)) {
       predv = res;
       pbuf[t & (CH - 1)] = res;
@@ -731,6 +760,12 @@ __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs
     __syncthreads();
     if (tid == 0) pout[t0] = (double)rounds;
   }
+#ifdef SACOPT_ABLATE
+  if (dbg & 2048) {  // DEBUG: histogram of the largest distance (in ulps) between guess and exact value over the boundaries of a sample
+    __syncthreads();
+    if (tid < 9) pout[t0 + tid] = (double)hist[tid];
+  }
+#endif
   if (st) {
 #pragma unroll
     for (int r = 0; r < R; r++)
@@ -762,19 +797,26 @@ __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs
 #define LPC_SNAP (LPC_TRI + LPC_N)        /* 324: packed lower triangle + b */
 #define LPC_RL 1024
 #define LPC_CH 512
+// The shipped profiles use LPC3/LPC2(alpha, S = 16, D = 8): N = 24 (profile.cpp:5,49,116). The kernels are templates over
+// (N, S) -- the reference's classes take S and D as constructor arguments (lpc.h:181,257) -- and are also instantiated for
+// N = 32, S = 24 (SACOPT_PROFILE_HIGH32: BASELINE configs[4]'s "32-tap OLS").
+#define LPC_TRI_(N) ((N) * ((N) + 1) / 2)
+#define LPC_SNAP_(N) (LPC_TRI_(N) + (N))
+#define LPC_COV_NT(N) (((LPC_SNAP_(N) + 63) / 64) * 64) /* threads of k_cov: one per covariance / b element (384, 576) */
 __device__ __forceinline__ int32_t s2u(int32_t v) { return v < 0 ? 2 * (-v) : (v > 0 ? 2 * v - 1 : 0); }
 
 // hist[i] at time t for channel ch (cov.h:44-47 shifts expressed as indices into the inputs)
+template <int S>
 __device__ __forceinline__ double lpc_hist(const int32_t *own, const int32_t *oth, int lagb, int i, int t) {
-  const int idx = (i < LPC_S) ? (t - 1 - i) : (t - lagb - (i - LPC_S));
-  const int32_t *src = (i < LPC_S) ? own : oth;
+  const int idx = (i < S) ? (t - 1 - i) : (t - lagb - (i - S));
+  const int32_t *src = (i < S) ? own : oth;
   return idx >= 0 ? (double)src[idx] : 0.;
 }
 
 // AutoCov::UpdateCov/UpdateB (cov.h:19-43), snapshot after every KS-th Update (lpc.h:213-219)
-template <int KS>
-__global__ __launch_bounds__(384) void k_cov(const LpcJob *__restrict__ jobs) {
-  constexpr int N = LPC_N, S = LPC_S, RL = LPC_RL, M = RL - 1, CH = LPC_CH;
+template <int KS, int N, int S>
+__global__ __launch_bounds__(LPC_COV_NT(N)) void k_cov(const LpcJob *__restrict__ jobs) {
+  constexpr int RL = LPC_RL, M = RL - 1, CH = LPC_CH, TRI = LPC_TRI_(N), SNAP = LPC_SNAP_(N), NT = LPC_COV_NT(N);
   __shared__ double ring[2][RL];
   const LpcJob &job = jobs[blockIdx.x];
   const int ch = blockIdx.y, oc = 1 - ch, lagb = (ch == 0) ? 1 : 0;
@@ -783,21 +825,21 @@ __global__ __launch_bounds__(384) void k_cov(const LpcJob *__restrict__ jobs) {
   const int32_t *s0 = job.s[0], *s1 = job.s[1];
   double *snap = ch ? job.snap[1] : job.snap[0];
   double *cst = ch ? job.cstate[1] : job.cstate[0];
-  for (int i = tid; i < 2 * RL; i += 384) (&ring[0][0])[i] = 0.;
+  for (int i = tid; i < 2 * RL; i += NT) (&ring[0][0])[i] = 0.;
   if (t0 > 0) {  // history before the chunk
     __syncthreads();
-    for (int idx = tid; idx < 2 * (RL - CH); idx += 384) {
+    for (int idx = tid; idx < 2 * (RL - CH); idx += NT) {
       const int c = idx / (RL - CH), tau = t0 - (RL - CH) + (idx - c * (RL - CH));
       const int32_t *ss = c ? s1 : s0;
       if (tau >= 0) ring[c][tau & M] = (double)ss[tau];
     }
   }
-  // element e: e < 300 -> c[j][i] (packed j(j+1)/2+i); 300..323 -> b[e-300]
+  // element e: e < TRI -> c[j][i] (packed j(j+1)/2+i); TRI..SNAP-1 -> b[e-TRI]
   const int e = tid;
-  const bool isc = e < LPC_TRI, isb = !isc && e < LPC_SNAP;
+  const bool isc = e < TRI, isb = !isc && e < SNAP;
   int j = 0, i = 0;
   if (isc) { while ((j + 1) * (j + 2) / 2 <= e) j++; i = e - j * (j + 1) / 2; }
-  else if (isb) i = e - LPC_TRI;
+  else if (isb) i = e - TRI;
   auto haddr = [&](int q) -> int {
     if (q < S) return ((-(1 + q)) & M) | (ch << 16);
     return ((-(lagb + (q - S))) & M) | (oc << 16);
@@ -808,7 +850,7 @@ __global__ __launch_bounds__(384) void k_cov(const LpcJob *__restrict__ jobs) {
   for (int t = t0; t < n; t++) {
     if ((t & (CH - 1)) == 0) {
       __syncthreads();
-      for (int idx = tid; idx < 2 * CH; idx += 384) {
+      for (int idx = tid; idx < 2 * CH; idx += NT) {
         const int c = idx / CH, k = idx - c * CH, tau = t + k;
         const int32_t *ss = c ? s1 : s0;
         ring[c][tau & M] = (tau < n) ? (double)ss[tau] : 0.;
@@ -819,25 +861,26 @@ __global__ __launch_bounds__(384) void k_cov(const LpcJob *__restrict__ jobs) {
     const double hj = isc ? ring[aj >> 16][(t + (aj & 0xffff)) & M] : ring[ch][t & M];  // b: val*hist[i]
     if (isc) cv = alpha * cv + (hi * hj);
     else if (isb) cv = alpha * cv + (hj * hi);
-    if (((t + 1) % KS) == 0 && (isc || isb)) snap[(size_t)(t / KS) * LPC_SNAP + e] = cv;
+    if (((t + 1) % KS) == 0 && (isc || isb)) snap[(size_t)(t / KS) * SNAP + e] = cv;
   }
   if (cst && (isc || isb)) cst[e] = cv;
 }
 
 // Cholesky::Factor + Solve for one snapshot (cholesky.cpp:16-77). Lane r owns matrix row r;
-// lane 24 carries CalcY (:37-46) as an extra row. Each scalar's inner sum runs in the
+// lane N carries CalcY (:37-46) as an extra row. Each scalar's inner sum runs in the
 // reference's k order. FAST: full-order Solve(b,x) only, regp = 0; else all orders, regp = 500.
-template <bool FAST>
+template <bool FAST, int N = LPC_N>
 __device__ __forceinline__ bool chol_wave(const double *snap, double *solo, int lane) {  // true = "matrix indefinit", solo untouched
-  constexpr int N = LPC_N;
+  constexpr int TRI = LPC_TRI_(N);
   constexpr double REGP = FAST ? 0. : 500.;
+  static_assert(N < 64, "one lane per matrix row + one for CalcY");
   double m[N];
   const int row = lane <= N ? lane : 0;
 #pragma unroll
   for (int q = 0; q < N; q++) {
     double v = 0.;
     if (row < N) { if (q <= row) v = snap[row * (row + 1) / 2 + q]; }
-    else v = snap[LPC_TRI + q];
+    else v = snap[TRI + q];
     if (q == lane) v += REGP;  // cholesky.cpp:20
     m[q] = v;
   }
@@ -891,15 +934,15 @@ __device__ __forceinline__ bool chol_wave(const double *snap, double *solo, int 
   }
   return false;
 }
-template <bool FAST>
+template <bool FAST, int N>
 __global__ __launch_bounds__(64) void k_chol(const LpcJob *__restrict__ jobs) {
   const LpcJob &job = jobs[blockIdx.y >> 1];
   const int ch = blockIdx.y & 1, k = job.t0 / (FAST ? 32 : 8) + blockIdx.x, lane = threadIdx.x;
   if (k >= job.nsnap) return;
-  const double *snap = (ch ? job.snap[1] : job.snap[0]) + (size_t)k * LPC_SNAP;
-  double *solo = (ch ? job.sol[1] : job.sol[0]) + (size_t)k * (FAST ? LPC_N : LPC_TRI);
+  const double *snap = (ch ? job.snap[1] : job.snap[0]) + (size_t)k * LPC_SNAP_(N);
+  double *solo = (ch ? job.sol[1] : job.sol[0]) + (size_t)k * (FAST ? N : LPC_TRI_(N));
   int32_t *failo = (ch ? job.fail[1] : job.fail[0]) + k;
-  const bool fail = chol_wave<FAST>(snap, solo, lane);
+  const bool fail = chol_wave<FAST, N>(snap, solo, lane);
   if (lane == 0) *failo = fail ? 1 : 0;
 }
 
@@ -912,28 +955,30 @@ __device__ __forceinline__ int lpc_sol_index(const int32_t *fail, int t) {
 }
 
 // LPC3::Predict all-orders sums (lpc.h:195-199): thread per (t, order)
+template <int N, int S>
 __global__ __launch_bounds__(256) void k_ssum(const LpcJob *__restrict__ jobs) {
   const LpcJob &job = jobs[blockIdx.y >> 1];
   const int ch = blockIdx.y & 1, n = job.n;
   const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
-  const int t = job.t0 + (int)(gid / LPC_N), o = (int)(gid % LPC_N);
+  const int t = job.t0 + (int)(gid / N), o = (int)(gid % N);
   if (t >= n) return;
   const int32_t *own = ch ? job.s[1] : job.s[0], *oth = ch ? job.s[0] : job.s[1];
   const int lagb = (ch == 0) ? 1 : 0;
   const int k = lpc_sol_index<8>(ch ? job.fail[1] : job.fail[0], t);
   double sum = 0.;
   if (k >= 0) {
-    const double *sol = (ch ? job.sol[1] : job.sol[0]) + (size_t)k * LPC_TRI + o * (o + 1) / 2;
-    for (int i = 0; i <= o; i++) sum += sol[i] * lpc_hist(own, oth, lagb, i, t);
+    const double *sol = (ch ? job.sol[1] : job.sol[0]) + (size_t)k * LPC_TRI_(N) + o * (o + 1) / 2;
+    for (int i = 0; i <= o; i++) sum += sol[i] * lpc_hist<S>(own, oth, lagb, i, t);
   }
-  (ch ? job.ss[1] : job.ss[0])[(size_t)t * LPC_N + o] = sum;
+  (ch ? job.ss[1] : job.ss[0])[(size_t)t * N + o] = sum;
 }
 
 // BlendErr running squared errors (blend.h:32-35): serial in t, lane per order
+template <int N>
 __global__ __launch_bounds__(64) void k_serr(const LpcJob *__restrict__ jobs) {
   const LpcJob &job = jobs[blockIdx.x];
   const int ch = blockIdx.y, lane = threadIdx.x, n = job.n;
-  if (lane >= LPC_N) return;
+  if (lane >= N) return;
   const int32_t *own = ch ? job.s[1] : job.s[0];
   const double *ss = ch ? job.ss[1] : job.ss[0];
   double *so = ch ? job.serr[1] : job.serr[0];
@@ -944,48 +989,49 @@ __global__ __launch_bounds__(64) void k_serr(const LpcJob *__restrict__ jobs) {
     double q[8];
 #pragma unroll
     for (int u = 0; u < 8; u++) {
-      const double e = ((double)own[t + u] - ss[(size_t)(t + u) * LPC_N + lane]);
+      const double e = ((double)own[t + u] - ss[(size_t)(t + u) * N + lane]);
       q[u] = (1. - 0.98) * (e * e);
     }
 #pragma unroll
     for (int u = 0; u < 8; u++) {
       serr = 0.98 * serr + q[u];
-      so[(size_t)(t + u) * LPC_N + lane] = serr;
+      so[(size_t)(t + u) * N + lane] = serr;
     }
   }
   for (; t < n; t++) {
-    const double e = ((double)own[t] - ss[(size_t)t * LPC_N + lane]);
+    const double e = ((double)own[t] - ss[(size_t)t * N + lane]);
     serr = 0.98 * serr + (1. - 0.98) * (e * e);
-    so[(size_t)t * LPC_N + lane] = serr;
+    so[(size_t)t * N + lane] = serr;
   }
   if (est) est[lane] = serr;
 }
 
 // BlendErr weights (blend.h:38-45) + blended prediction (blend.h:15-17): thread per t
+template <int N>
 __global__ __launch_bounds__(256) void k_pm(const LpcJob *__restrict__ jobs) {
   const LpcJob &job = jobs[blockIdx.y >> 1];
   const int ch = blockIdx.y & 1, n = job.n;
   const int t = job.t0 + blockIdx.x * 256 + threadIdx.x;
   if (t >= n) return;
   const int32_t *own = ch ? job.s[1] : job.s[0];
-  const double *ss = (ch ? job.ss[1] : job.ss[0]) + (size_t)t * LPC_N;
+  const double *ss = (ch ? job.ss[1] : job.ss[0]) + (size_t)t * N;
   double pm = 0.;
   if (t > 0) {  // weights as left by Update(t-1); before the first update they are all zero
-    const double *se = (ch ? job.serr[1] : job.serr[0]) + (size_t)(t - 1) * LPC_N;
-    double w[LPC_N];
+    const double *se = (ch ? job.serr[1] : job.serr[0]) + (size_t)(t - 1) * N;
+    double w[N];
     double wsum = 0;
 #pragma unroll
-    for (int i = 0; i < LPC_N; i++) {
+    for (int i = 0; i < N; i++) {
       const double tt = 10000. / (se[i] + 0.0001);
       w[i] = tt * tt;
       wsum += w[i];
     }
     if (wsum > 0) {
 #pragma unroll
-      for (int i = 0; i < LPC_N; i++) w[i] /= wsum;
+      for (int i = 0; i < N; i++) w[i] /= wsum;
     }
 #pragma unroll
-    for (int i = 0; i < LPC_N; i++) pm += w[i] * ss[i];
+    for (int i = 0; i < N; i++) pm += w[i] * ss[i];
   }
   const double v = (double)own[t];
   (ch ? job.p[1] : job.p[0])[t] = pm;
@@ -1004,7 +1050,7 @@ __global__ __launch_bounds__(256) void k_pred2(const LpcJob *__restrict__ jobs) 
   double p = 0.;
   if (k >= 0) {
     const double *sol = (ch ? job.sol[1] : job.sol[0]) + (size_t)k * LPC_N;
-    for (int i = 0; i < LPC_N; i++) p += sol[i] * lpc_hist(own, oth, lagb, i, t);
+    for (int i = 0; i < LPC_N; i++) p += sol[i] * lpc_hist<LPC_S>(own, oth, lagb, i, t);
   }
   const int32_t e = cvt_i32_x86((double)own[t] - round(p));
   const int32_t ue = s2u(e);
@@ -1389,24 +1435,29 @@ extern "C" int sacopt_lms_state_doubles(int S, int D) {  // 2 * R * NT of the ma
 // (14k against 10k CU-cycles): right while the call is bound by the latency of a few chains (the 60 s clip: 15), wrong once
 // the optimizer's rounds fill the chip (measured, frames per call: 24: 888 against 860 ms, 30: 1036 against 922, 75: 2130
 // against 2020 with the two-channel kernel everywhere).
+#ifdef SACOPT_ABLATE
+#define ABL_SW(bits) ((bits) >> 8)  // kernel-variant switches of tools/ builds
+#else
+#define ABL_SW(bits) 0
+#endif
 extern "C" int sacopt_lms_variant(int S, int D, int njobs, int bits) {
   if (S != 1280 || D != 640) return 0;
-  return (!((bits >> 8) & (8 | 256)) && (njobs <= 20 || ((bits >> 8) & 512))) ? 1 : 0;
+  return (!(ABL_SW(bits) & (8 | 256)) && (njobs <= 20 || (ABL_SW(bits) & 512))) ? 1 : 0;
 }
 extern "C" int sacopt_launch_lms(int S, int D, const LmsJob *jobs, int njobs, const uint16_t *tab, int bits,
                                  hipStream_t st) {
   if (njobs <= 0) return 0;
   if (S == 1280 && D == 640) {
     if (sacopt_lms_variant(S, D, njobs, bits)) hipLaunchKernelGGL(k_lms1c, dim3(2 * njobs), dim3(L1_NT), 0, st, jobs, tab, bits);
-    else if ((bits >> 8) & 8) hipLaunchKernelGGL((k_lms<1280, 640, 1024, 4, 2048, false>), dim3(njobs), dim3(1024), 0, st, jobs, tab, bits);
+    else if (ABL_SW(bits) & 8) hipLaunchKernelGGL((k_lms<1280, 640, 1024, 4, 2048, false>), dim3(njobs), dim3(1024), 0, st, jobs, tab, bits);
     // 1024 threads are faster for a chain alone (9.4k against 10.0k cycles per sample) but slower in the optimizer's
     // rounds, where the follower stages want room on the same CUs (optimize 571 against 526 ms): A/B switch only
-    else if ((bits >> 8) & 4096) hipLaunchKernelGGL((k_lms<1280, 640, 1024, 4, 2048, true>), dim3(njobs), dim3(1024), 0, st, jobs, tab, bits);
+    else if (ABL_SW(bits) & 4096) hipLaunchKernelGGL((k_lms<1280, 640, 1024, 4, 2048, true>), dim3(njobs), dim3(1024), 0, st, jobs, tab, bits);
     else hipLaunchKernelGGL((k_lms<1280, 640, 512, 8, 2048, true>), dim3(njobs), dim3(512), 0, st, jobs, tab, bits);
   }
   // follower stages: short rings (128 samples per refill) keep their LDS small, so that more of them share a CU and
   // fit beside a lead workgroup (A/B switch 8192: the 512-sample instances)
-  else if ((bits >> 8) & 8192) {
+  else if (ABL_SW(bits) & 8192) {
     if (S == 256 && D == 128) hipLaunchKernelGGL((k_lms<256, 128, 256, 3, 1024, false>), dim3(njobs), dim3(256), 0, st, jobs, tab, bits);
     else if (S == 32 && D == 16) hipLaunchKernelGGL((k_lms<32, 16, 64, 2, 1024, false>), dim3(njobs), dim3(64), 0, st, jobs, tab, bits);
     else if (S == 8 && D == 4) hipLaunchKernelGGL((k_lms<8, 4, 64, 1, 1024, false>), dim3(njobs), dim3(64), 0, st, jobs, tab, bits);
@@ -1419,21 +1470,28 @@ extern "C" int sacopt_launch_lms(int S, int D, const LmsJob *jobs, int njobs, co
   return hipGetLastError() != hipSuccess;
 }
 // max_n: longest span n - t0 of the jobs
-extern "C" int sacopt_launch_lpc3(const LpcJob *jobs, int njobs, int max_n, hipStream_t st) {
-  if (njobs <= 0 || max_n <= 0) return 0;
+template <int N, int S>
+static int launch_lpc3_ns(const LpcJob *jobs, int njobs, int max_n, hipStream_t st) {
   const int max_snap = max_n / 8;
-  hipLaunchKernelGGL(k_cov<8>, dim3(njobs, 2), dim3(384), 0, st, jobs);
-  if (max_snap) hipLaunchKernelGGL(k_chol<false>, dim3(max_snap, 2 * njobs), dim3(64), 0, st, jobs);
-  hipLaunchKernelGGL(k_ssum, dim3((unsigned)(((long long)max_n * LPC_N + 255) / 256), 2 * njobs), dim3(256), 0, st, jobs);
-  hipLaunchKernelGGL(k_serr, dim3(njobs, 2), dim3(64), 0, st, jobs);
-  hipLaunchKernelGGL(k_pm, dim3((max_n + 255) / 256, 2 * njobs), dim3(256), 0, st, jobs);
+  hipLaunchKernelGGL((k_cov<8, N, S>), dim3(njobs, 2), dim3(LPC_COV_NT(N)), 0, st, jobs);
+  if (max_snap) hipLaunchKernelGGL((k_chol<false, N>), dim3(max_snap, 2 * njobs), dim3(64), 0, st, jobs);
+  hipLaunchKernelGGL((k_ssum<N, S>), dim3((unsigned)(((long long)max_n * N + 255) / 256), 2 * njobs), dim3(256), 0, st, jobs);
+  hipLaunchKernelGGL((k_serr<N>), dim3(njobs, 2), dim3(64), 0, st, jobs);
+  hipLaunchKernelGGL((k_pm<N>), dim3((max_n + 255) / 256, 2 * njobs), dim3(256), 0, st, jobs);
   return hipGetLastError() != hipSuccess;
+}
+// ols_n: S + D of LPC3 (24 = the shipped profiles' (16,8); 32 = (24,8))
+extern "C" int sacopt_launch_lpc3(const LpcJob *jobs, int njobs, int max_n, int ols_n, hipStream_t st) {
+  if (njobs <= 0 || max_n <= 0) return 0;
+  if (ols_n == 24) return launch_lpc3_ns<24, 16>(jobs, njobs, max_n, st);
+  if (ols_n == 32) return launch_lpc3_ns<32, 24>(jobs, njobs, max_n, st);
+  return 1;
 }
 extern "C" int sacopt_launch_lpc2(const LpcJob *jobs, int njobs, int max_n, hipStream_t st) {
   if (njobs <= 0 || max_n <= 0) return 0;
   const int max_snap = max_n / 32;
-  hipLaunchKernelGGL(k_cov<32>, dim3(njobs, 2), dim3(384), 0, st, jobs);
-  if (max_snap) hipLaunchKernelGGL(k_chol<true>, dim3(max_snap, 2 * njobs), dim3(64), 0, st, jobs);
+  hipLaunchKernelGGL((k_cov<32, LPC_N, LPC_S>), dim3(njobs, 2), dim3(LPC_COV_NT(LPC_N)), 0, st, jobs);
+  if (max_snap) hipLaunchKernelGGL((k_chol<true, LPC_N>), dim3(max_snap, 2 * njobs), dim3(64), 0, st, jobs);
   hipLaunchKernelGGL(k_pred2, dim3((max_n + 255) / 256, 2 * njobs), dim3(256), 0, st, jobs);
   return hipGetLastError() != hipSuccess;
 }

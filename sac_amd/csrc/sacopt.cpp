@@ -24,7 +24,7 @@ extern "C" {
 int sacopt_lms_state_doubles(int S, int D);
 int sacopt_launch_lms(int S, int D, const LmsJob *jobs, int njobs, const uint16_t *tab, int bits, hipStream_t st);
 int sacopt_lms_variant(int S, int D, int njobs, int bits);
-int sacopt_launch_lpc3(const LpcJob *jobs, int njobs, int max_n, hipStream_t st);
+int sacopt_launch_lpc3(const LpcJob *jobs, int njobs, int max_n, int ols_n, hipStream_t st);
 int sacopt_launch_lpc2(const LpcJob *jobs, int njobs, int max_n, hipStream_t st);
 int sacopt_launch_mix(int ns, const MixJob *jobs, int njobs, hipStream_t st);
 int sacopt_launch_cost(const CostJob *jobs, int njobs, const int *pow2_bits, hipStream_t st);
@@ -55,12 +55,24 @@ struct sacopt_ctx {
   // bump arena (device)
   char *arena = nullptr;
   size_t cap = 0, used = 0;
+  // pinned host staging for job tables and other small uploads: hipMemcpyAsync reads it after the enqueueing function has
+  // returned, so it lives in the context until the next call has synchronised every stream (begin_call)
+  struct PinBlock { char *p; size_t cap, used; };
+  std::vector<PinBlock> pins;
   // timing of the last call
   std::vector<std::pair<hipEvent_t, hipEvent_t>> lms_ev;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   double total_ms = 0, lms_ms = 0;
   int lms_launches = 0;
   long long lms_units = 0;  // stereo samples processed by the timed launches
+  // residual buffers of the last sacopt_get_costs call (still in the arena), for sacopt_recost_last
+  struct Kept {
+    bool valid = false;
+    int nframes = 0, ncand = 0;
+    std::vector<const int32_t *> bufs;  // [frame][cand][channel]
+    std::vector<int> n;                 // window length per frame
+    size_t mark = 0;                    // arena position behind the kept data
+  } kept;
 };
 
 #define HIPCK(ctx, call)                                                                          \
@@ -135,6 +147,7 @@ extern "C" int sacopt_probe_rsqrt(float *tab, int cap) {
 struct StageDesc { int S, D, c1, c2; };
 struct ProfDesc {
   int type, ncoef, nlms;
+  int ols_n;       // taps of the OLS stage (S + D): 24 for the reference's profiles, 32 for SACOPT_PROFILE_HIGH32
   StageDesc lms[4];
   int cmix;        // coefficient index of the RLS alpha
   int nprefix[6];  // coefs that determine the output of stage s (0 = LPC, 1..nlms = LMS, nlms+1 = mixer)
@@ -143,7 +156,8 @@ struct ProfDesc {
 static bool get_prof(int type, ProfDesc *p) {
   memset(p, 0, sizeof(*p));
   p->type = type;
-  if (type == SACOPT_PROFILE_HIGH) {  // StereoHigh ctor, src/profile.cpp:113-124
+  p->ols_n = (type == SACOPT_PROFILE_HIGH32) ? 32 : 24;
+  if (type == SACOPT_PROFILE_HIGH || type == SACOPT_PROFILE_HIGH32) {  // StereoHigh ctor, src/profile.cpp:113-124 (HIGH32: LPC3(alpha, 24, 8, 8, 500))
     p->ncoef = 8; p->nlms = 4;
     p->lms[0] = {1280, 640, 1, 2}; p->lms[1] = {256, 128, 3, 4}; p->lms[2] = {32, 16, 5, 5}; p->lms[3] = {8, 4, 6, 6};
     p->cmix = 7;
@@ -177,7 +191,7 @@ extern "C" int sacopt_base_profile(int profile, double *out) {  // src/codec.cpp
   int n;
   if (profile == 0) { src = &fast[0][0]; n = 1; }
   else if (profile == 1) { src = &normal[0][0]; n = 6; }
-  else if (profile == 2) { src = &high[0][0]; n = 8; }
+  else if (profile == 2 || profile == SACOPT_PROFILE_HIGH32) { src = &high[0][0]; n = 8; }
   else return 0;
   for (int i = 0; i < 3 * n; i++) out[i] = src[i];
   return n;
@@ -207,7 +221,9 @@ extern "C" int sacopt_create(int device, const float *rsqrt_tab, int rsqrt_bits,
   sacopt_ctx *c = new sacopt_ctx;
   c->device = device;
   c->bits = bits;
-  if (const char *dbg = getenv("SACOPT_DBG_ALL")) c->bits |= atoi(dbg) << 8;  // kernel-variant switches for A/B timing (kernels.hip)
+#ifdef SACOPT_ABLATE  // tools/ builds only: kernel-variant switches for A/B timing (kernels.hip). The product library reads no such variable.
+  if (const char *dbg = getenv("SACOPT_DBG_ALL")) c->bits |= atoi(dbg) << 8;
+#endif
   auto fail = [&](const char *what) { g_create_error = what; delete c; return 1; };
   if (hipSetDevice(device) != hipSuccess) return fail("hipSetDevice failed");
   // Streams and hardware queues. HIP multiplexes same-priority streams onto a small pool of in-order hardware
@@ -276,7 +292,7 @@ extern "C" int sacopt_create(int device, const float *rsqrt_tab, int rsqrt_bits,
   for (int i = 0; i < (2 << bits); i++) {
     uint32_t u;
     memcpy(&u, &tab[i], 4);
-    if (!RSQ_PACKABLE(u)) return fail("rsqrtss table entry outside [0.5,1) or with more than 16 significant bits: not an rsqrtss table");
+    if (!RSQ_PACKABLE(u)) return fail("rsqrtss table entry outside [0.5,2) or with more than 16 significant bits: not an rsqrtss table");
     packed[i] = RSQ_PACK(u);
   }
   if (hipMalloc(&c->d_tab, sizeof(uint16_t) * (2 << bits)) != hipSuccess) return fail("hipMalloc(table) failed");
@@ -299,6 +315,7 @@ extern "C" void sacopt_destroy(sacopt_ctx *c) {
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->arena) (void)hipFree(c->arena);
+  for (auto &b : c->pins) (void)hipHostFree(b.p);
   if (c->d_tab) (void)hipFree(c->d_tab);
   if (c->d_pow2) (void)hipFree(c->d_pow2);
   for (hipEvent_t e : c->pipe_ev) (void)hipEventDestroy(e);
@@ -345,12 +362,34 @@ static bool is_device_ptr(const void *p) {
   if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
   return a.type == hipMemoryTypeDevice;
 }
+// Pinned staging memory that stays valid until the next call's begin_call (see sacopt_ctx::pins).
+static void *pin_alloc(sacopt_ctx *c, size_t bytes) {
+  bytes = (bytes + 255) & ~(size_t)255;
+  if (!c->pins.empty()) {
+    auto &b = c->pins.back();
+    if (b.used + bytes <= b.cap) { void *p = b.p + b.used; b.used += bytes; return p; }
+  }
+  size_t cap = c->pins.empty() ? ((size_t)4 << 20) : 2 * c->pins.back().cap;
+  if (cap < bytes) cap = bytes;
+  char *p = nullptr;
+  if (hipHostMalloc((void **)&p, cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  c->pins.push_back({p, cap, bytes});
+  return p;
+}
+// host bytes -> device, asynchronously on `s`, through pinned staging (the source may go away as soon as this returns)
+static int upload_bytes(sacopt_ctx *c, void *dst_dev, const void *src, size_t bytes, hipStream_t s) {
+  if (!bytes) return 0;
+  void *pin = pin_alloc(c, bytes);
+  if (!pin) { c->err = "hipHostMalloc (staging) failed"; return 1; }
+  memcpy(pin, src, bytes);
+  HIPCK(c, hipMemcpyAsync(dst_dev, pin, bytes, hipMemcpyHostToDevice, s));
+  return 0;
+}
 template <class T>
 static int upload(sacopt_ctx *c, const std::vector<T> &h, T **d) {
   *d = arena_alloc<T>(c, h.size() ? h.size() : 1);
   if (!*d) { c->err = "device arena exhausted"; return 1; }
-  if (h.size()) HIPCK(c, hipMemcpyAsync(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, c->up ? c->up : c->st));
-  return 0;
+  return upload_bytes(c, *d, h.data(), h.size() * sizeof(T), c->up ? c->up : c->st);
 }
 template <class T>
 static int to_dev(sacopt_ctx *c, const T *src, size_t count, const T **out) {
@@ -367,6 +406,15 @@ static int begin_call(sacopt_ctx *c) {
   // a call that failed half-way may have left work in flight on the pipeline streams; the arena is about to be reused
   for (hipStream_t s : {c->st, c->sA, c->sAall, c->sB, c->sC, c->sD, c->sE, c->split[0], c->split[1], c->split[2], c->split[3], c->split[4]})
     if (s) HIPCK(c, hipStreamSynchronize(s));
+  // nothing is in flight any more: the staging memory of the previous call can be reused (several blocks -> one of their size)
+  if (c->pins.size() > 1) {
+    size_t tot = 0;
+    for (auto &b : c->pins) { tot += b.cap; (void)hipHostFree(b.p); }
+    c->pins.clear();
+    char *p = nullptr;
+    if (hipHostMalloc((void **)&p, tot, hipHostMallocDefault) == hipSuccess) c->pins.push_back({p, tot, 0});
+    else (void)hipGetLastError();
+  } else if (!c->pins.empty()) c->pins[0].used = 0;
   for (auto &p : c->lms_ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   c->lms_ev.clear();
   for (hipEvent_t e : c->pipe_ev) (void)hipEventDestroy(e);
@@ -374,6 +422,7 @@ static int begin_call(sacopt_ctx *c) {
   c->total_ms = c->lms_ms = 0;
   c->lms_launches = 0;
   c->lms_units = 0;
+  c->kept.valid = false;  // the arena is about to be reused
   return 0;
 }
 static int end_timing(sacopt_ctx *c) {
@@ -426,25 +475,27 @@ static size_t chain_bytes(const ProfDesc &pd, int n) {
 }
 
 // LPC scratch (covariance snapshots, solutions, all-orders sums, running errors) for one chain
-static size_t lpc_scratch_bytes(int type, int n) {
+static size_t lpc_scratch_bytes(const ProfDesc &pd, int n) {
+  const int type = pd.type, N = pd.ols_n, tri = N * (N + 1) / 2;
   const int ks = (type == SACOPT_PROFILE_FAST) ? 32 : 8;
   const size_t nsnap = (size_t)n / ks;
   auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-  size_t per_ch = al(nsnap * 324 * 8) + al(nsnap * (type == SACOPT_PROFILE_FAST ? 24 : 300) * 8) + al(nsnap * 4 + 4);
-  if (type != SACOPT_PROFILE_FAST) per_ch += 2 * al((size_t)n * 24 * 8);
+  size_t per_ch = al(nsnap * (tri + N) * 8) + al(nsnap * (type == SACOPT_PROFILE_FAST ? N : tri) * 8) + al(nsnap * 4 + 4);
+  if (type != SACOPT_PROFILE_FAST) per_ch += 2 * al((size_t)n * N * 8);
   return 2 * per_ch + 1024;
 }
-static int lpc_scratch_alloc(sacopt_ctx *c, int type, LpcJob &j) {
+static int lpc_scratch_alloc(sacopt_ctx *c, const ProfDesc &pd, LpcJob &j) {
+  const int type = pd.type, N = pd.ols_n, tri = N * (N + 1) / 2;
   const int ks = (type == SACOPT_PROFILE_FAST) ? 32 : 8;
   j.nsnap = j.n / ks;
   for (int k = 0; k < 2; k++) {
-    j.snap[k] = arena_alloc<double>(c, (size_t)j.nsnap * 324);
-    j.sol[k] = arena_alloc<double>(c, (size_t)j.nsnap * (type == SACOPT_PROFILE_FAST ? 24 : 300));
+    j.snap[k] = arena_alloc<double>(c, (size_t)j.nsnap * (tri + N));
+    j.sol[k] = arena_alloc<double>(c, (size_t)j.nsnap * (type == SACOPT_PROFILE_FAST ? N : tri));
     j.fail[k] = arena_alloc<int32_t>(c, (size_t)j.nsnap + 1);
     if (!j.snap[k] || !j.sol[k] || !j.fail[k]) { c->err = "device arena exhausted (LPC scratch)"; return 1; }
     if (type != SACOPT_PROFILE_FAST) {
-      j.ss[k] = arena_alloc<double>(c, (size_t)j.n * 24);
-      j.serr[k] = arena_alloc<double>(c, (size_t)j.n * 24);
+      j.ss[k] = arena_alloc<double>(c, (size_t)j.n * N);
+      j.serr[k] = arena_alloc<double>(c, (size_t)j.n * N);
       if (!j.ss[k] || !j.serr[k]) { c->err = "device arena exhausted (LPC scratch)"; return 1; }
     }
   }
@@ -526,12 +577,11 @@ static int eval_chains(sacopt_ctx *c, const ProfDesc &pd, const std::vector<DevF
       // stream, and the full-frame pipeline, enqueued next on other streams, would have overwritten it -- a fault seen once)
       int max_n = 0;
       for (LpcJob &j : jobs) {
-        if (lpc_scratch_alloc(c, pd.type, j)) return 1;
+        if (lpc_scratch_alloc(c, pd, j)) return 1;
         max_n = j.n > max_n ? j.n : max_n;
         HIPCK(c, hipMemsetAsync(j.umax, 0, 8, c->st));
       }
-      HIPCK(c, hipMemcpyAsync(dj, jobs.data(), jobs.size() * sizeof(LpcJob), hipMemcpyHostToDevice, c->st));
-      HIPCK(c, hipStreamSynchronize(c->st));  // jobs vector is host-local
+      if (upload_bytes(c, dj, jobs.data(), jobs.size() * sizeof(LpcJob), c->st)) return 1;
       if (sacopt_launch_lpc2(dj, (int)jobs.size(), max_n, c->st)) { c->err = "LPC2 launch failed"; return 1; }
     } else if (s == 0) {
       std::vector<LpcJob> jobs;
@@ -549,12 +599,11 @@ static int eval_chains(sacopt_ctx *c, const ProfDesc &pd, const std::vector<DevF
       if (!dj) { c->err = "device arena exhausted"; return 1; }
       int max_n = 0;
       for (LpcJob &j : jobs) {
-        if (lpc_scratch_alloc(c, pd.type, j)) return 1;
+        if (lpc_scratch_alloc(c, pd, j)) return 1;
         max_n = j.n > max_n ? j.n : max_n;
       }
-      HIPCK(c, hipMemcpyAsync(dj, jobs.data(), jobs.size() * sizeof(LpcJob), hipMemcpyHostToDevice, c->st));
-      HIPCK(c, hipStreamSynchronize(c->st));
-      if (sacopt_launch_lpc3(dj, (int)jobs.size(), max_n, c->st)) { c->err = "LPC3 launch failed"; return 1; }
+      if (upload_bytes(c, dj, jobs.data(), jobs.size() * sizeof(LpcJob), c->st)) return 1;
+      if (sacopt_launch_lpc3(dj, (int)jobs.size(), max_n, pd.ols_n, c->st)) { c->err = "LPC3 launch failed"; return 1; }
     } else {
       todo_s[s] = todo;  // LMS stages and the mixer are launched below, pipelined over chunks
     }
@@ -643,7 +692,7 @@ static int eval_chains(sacopt_ctx *c, const ProfDesc &pd, const std::vector<DevF
   }
   char *d_tables = arena_alloc<char>(c, stg.host.size() + 256);
   if (!d_tables) { c->err = "device arena exhausted"; return 1; }
-  HIPCK(c, hipMemcpyAsync(d_tables, stg.host.data(), stg.host.size(), hipMemcpyHostToDevice, c->st));
+  if (upload_bytes(c, d_tables, stg.host.data(), stg.host.size(), c->st)) return 1;
   for (int k = 0; k < nchunk; k++) {
     std::vector<void *> d_jobs(nstage, nullptr);
     for (int s = lead; s < nstage; s++) d_jobs[s] = d_tables + o_jobs[k][s];
@@ -773,10 +822,10 @@ static int final_pass_enqueue(sacopt_ctx *c, const ProfDesc &pd, const std::vect
     for (int k = 0; k < 2; k++) { j.s[k] = f.s[k] + f.from; j.p[k] = ch.sb[0].p[k]; j.x1[k] = ch.sb[0].xn[k]; }
     j.alpha = ch.coefs[0];
     j.n = f.n;
-    if (lpc_scratch_alloc(c, pd.type, j)) return 1;  // stays allocated for the whole call
+    if (lpc_scratch_alloc(c, pd, j)) return 1;  // stays allocated for the whole call
     for (int k = 0; k < 2; k++) {  // the LPC stage is chunked too: covariance / BlendErr state carried
-      j.cstate[k] = arena_alloc<double>(c, 324);
-      j.estate[k] = arena_alloc<double>(c, 24);
+      j.cstate[k] = arena_alloc<double>(c, pd.ols_n * (pd.ols_n + 1) / 2 + pd.ols_n);
+      j.estate[k] = arena_alloc<double>(c, pd.ols_n);
       if (!j.cstate[k] || !j.estate[k]) { c->err = "device arena exhausted"; return 1; }
     }
   }
@@ -865,7 +914,7 @@ static int final_pass_enqueue(sacopt_ctx *c, const ProfDesc &pd, const std::vect
   {
     char *dev = arena_alloc<char>(c, stg.host.size() + 256);
     if (!dev) { c->err = "device arena exhausted"; return 1; }
-    HIPCK(c, hipMemcpyAsync(dev, stg.host.data(), stg.host.size(), hipMemcpyHostToDevice, c->up ? c->up : c->st));
+    if (upload_bytes(c, dev, stg.host.data(), stg.host.size(), c->up ? c->up : c->st)) return 1;
     for (int k = 0; k < nchunk; k++) {
       d_lpc[k] = reinterpret_cast<LpcJob *>(dev + o_lpc[k]);
       d_mix[k] = reinterpret_cast<MixJob *>(dev + o_mix[k]);
@@ -892,7 +941,7 @@ static int final_pass_enqueue(sacopt_ctx *c, const ProfDesc &pd, const std::vect
   std::vector<hipEvent_t> ev_lpc(nchunk, nullptr);
   auto lpc_chunk = [&](int k) -> int {
     if (k >= nchunk) return 0;
-    if (sacopt_launch_lpc3(d_lpc[k], n_lpc[k], len_lpc[k], c->sB)) { c->err = "LPC3 launch failed"; return 1; }
+    if (sacopt_launch_lpc3(d_lpc[k], n_lpc[k], len_lpc[k], pd.ols_n, c->sB)) { c->err = "LPC3 launch failed"; return 1; }
     if (new_event(&ev_lpc[k])) return 1;
     HIPCK(c, hipEventRecord(ev_lpc[k], c->sB));
     return 0;
@@ -954,6 +1003,17 @@ static int run_final_pass(sacopt_ctx *c, const ProfDesc &pd, const std::vector<D
     return eval_chains(c, pd, fr, chains, memo);
   }
   return final_pass_enqueue(c, pd, fr, chains, done, staged);
+}
+
+// Caller-supplied frames and windows, checked BEFORE anything is sized from them (64-bit arithmetic: from + n may overflow int)
+static int check_frames(sacopt_ctx *c, int nframes, const sacopt_frame *frames, const int32_t *from, const int32_t *n) {
+  for (int f = 0; f < nframes; f++) {
+    const long long ns = frames[f].numsamples, fr = from ? from[f] : 0, nn = n ? n[f] : ns - fr;
+    if (ns < 0) { c->err = "negative numsamples"; return 1; }
+    if (fr < 0 || nn < 0 || fr + nn > ns) { c->err = "window outside frame"; return 1; }
+    if (ns && (!frames[f].s0 || !frames[f].s1)) { c->err = "null sample pointer"; return 1; }
+  }
+  return 0;
 }
 
 // Stage input frames: device pointers are used in place, host pointers are copied into the arena.
@@ -1064,13 +1124,14 @@ extern "C" int sacopt_predict_stereo_frames(sacopt_ctx *c, int profile, int nfra
   ProfDesc pd;
   if (!get_prof(profile, &pd)) { c->err = "unknown profile"; return 1; }
   if (nframes < 0 || (nframes && (!frames || !out))) { c->err = "bad arguments"; return 1; }
+  if (check_frames(c, nframes, frames, from, n)) return 1;
   double base[3 * SACOPT_MAX_COEFS];
   sacopt_base_profile(profile, base);
   size_t need = 1 << 20;
   for (int f = 0; f < nframes; f++) {
     const int nn = n ? n[f] : frames[f].numsamples - (from ? from[f] : 0);
     need += chain_bytes(pd, nn > 0 ? nn : 0) + 2 * (((size_t)frames[f].numsamples * 4 + 255) & ~(size_t)255) + 4096 +
-            lpc_scratch_bytes(pd.type, nn > 0 ? nn : 0) + sizeof(LpcJob) + 256 + pipe_bytes(nn > 0 ? nn : 0) +
+            lpc_scratch_bytes(pd, nn > 0 ? nn : 0) + sizeof(LpcJob) + 256 + pipe_bytes(nn > 0 ? nn : 0) +
             ((out[f].map0 || out[f].map1) ? map_bytes(nn > 0 ? nn : 0) : 0);
   }
   if (arena_reserve(c, need)) return 1;
@@ -1090,17 +1151,9 @@ extern "C" int sacopt_predict_stereo_frames(sacopt_ctx *c, int profile, int nfra
 
 // ------------------------------------------------------------------------------------------ GetCost / Optimize
 // Cost of `ncand` candidates per frame, in order, CostGolomb state carried (d_state[f]).
-static int cost_round(sacopt_ctx *c, const ProfDesc &pd, const std::vector<DevFrame> &fr, const std::vector<Chain> &chains,
-                      int ncand, double *d_state, std::vector<double> &costs_host) {
-  const int nframes = (int)fr.size();
-  const int last = (pd.type == SACOPT_PROFILE_FAST) ? 0 : pd.nlms + 1;
-  std::vector<const int32_t *> bufs(2 * (size_t)nframes * ncand);
-  for (int f = 0; f < nframes; f++)
-    for (int k = 0; k < ncand; k++) {
-      const Chain &ch = chains[(size_t)f * ncand + k];
-      bufs[2 * ((size_t)f * ncand + k)] = ch.sb[last].e[0];
-      bufs[2 * ((size_t)f * ncand + k) + 1] = ch.sb[last].e[1];
-    }
+// bufs: residual buffers [frame][cand][channel] on the device; ns: window length per frame.
+static int cost_round_bufs(sacopt_ctx *c, int nframes, int ncand, const std::vector<const int32_t *> &bufs, const std::vector<int> &ns,
+                           double *d_state, std::vector<double> &costs_host) {
   const int32_t **d_bufs;
   if (upload(c, bufs, &d_bufs)) return 1;
   double *d_costs = arena_alloc<double>(c, (size_t)nframes * ncand);
@@ -1110,7 +1163,7 @@ static int cost_round(sacopt_ctx *c, const ProfDesc &pd, const std::vector<DevFr
     jobs[f].bufs = d_bufs + 2 * (size_t)f * ncand;
     jobs[f].costs = d_costs + (size_t)f * ncand;
     jobs[f].state = d_state + f;
-    jobs[f].n = fr[f].n;
+    jobs[f].n = ns[f];
     jobs[f].nbuf = 2 * ncand;
     jobs[f].scr = arena_alloc<double>(c, 6 * (size_t)ncand);
     jobs[f].ok = arena_alloc<int32_t>(c, 1);
@@ -1124,6 +1177,28 @@ static int cost_round(sacopt_ctx *c, const ProfDesc &pd, const std::vector<DevFr
   HIPCK(c, hipStreamSynchronize(c->st));
   return 0;
 }
+static void chain_bufs(const ProfDesc &pd, const std::vector<DevFrame> &fr, const std::vector<Chain> &chains, int ncand,
+                       std::vector<const int32_t *> &bufs, std::vector<int> &ns) {
+  const int nframes = (int)fr.size();
+  const int last = (pd.type == SACOPT_PROFILE_FAST) ? 0 : pd.nlms + 1;
+  bufs.resize(2 * (size_t)nframes * ncand);
+  ns.resize(nframes);
+  for (int f = 0; f < nframes; f++) {
+    ns[f] = fr[f].n;
+    for (int k = 0; k < ncand; k++) {
+      const Chain &ch = chains[(size_t)f * ncand + k];
+      bufs[2 * ((size_t)f * ncand + k)] = ch.sb[last].e[0];
+      bufs[2 * ((size_t)f * ncand + k) + 1] = ch.sb[last].e[1];
+    }
+  }
+}
+static int cost_round(sacopt_ctx *c, const ProfDesc &pd, const std::vector<DevFrame> &fr, const std::vector<Chain> &chains,
+                      int ncand, double *d_state, std::vector<double> &costs_host) {
+  std::vector<const int32_t *> bufs;
+  std::vector<int> ns;
+  chain_bufs(pd, fr, chains, ncand, bufs, ns);
+  return cost_round_bufs(c, (int)fr.size(), ncand, bufs, ns, d_state, costs_host);
+}
 
 extern "C" int sacopt_get_costs(sacopt_ctx *c, int profile, int nframes, const sacopt_frame *frames, const int32_t *from,
                                 const int32_t *n, int ncand, const double *cand_coefs, double *costs, double *cost_state) {
@@ -1133,11 +1208,13 @@ extern "C" int sacopt_get_costs(sacopt_ctx *c, int profile, int nframes, const s
   if (!get_prof(profile, &pd)) { c->err = "unknown profile"; return 1; }
   if (nframes < 0 || ncand < 0 || (nframes && ncand && (!frames || !cand_coefs || !costs))) { c->err = "bad arguments"; return 1; }
   if (!nframes || !ncand) return 0;
+  if (check_frames(c, nframes, frames, from, n)) return 1;
   size_t need = 1 << 20;
   for (int f = 0; f < nframes; f++) {
     const int nn = n ? n[f] : frames[f].numsamples - (from ? from[f] : 0);
     need += (size_t)ncand * chain_bytes(pd, nn > 0 ? nn : 0) + 2 * (((size_t)frames[f].numsamples * 4 + 255) & ~(size_t)255) + 4096 +
-            (size_t)ncand * (64 + lpc_scratch_bytes(pd.type, nn > 0 ? nn : 0) + sizeof(LpcJob) + 256);
+            (size_t)ncand * (64 + lpc_scratch_bytes(pd, nn > 0 ? nn : 0) + sizeof(LpcJob) + 256) +
+            2 * ((size_t)ncand * (16 + 8 + 48) + sizeof(CostJob) + 2048);  // cost tables, twice: one more set for sacopt_recost_last
   }
   if (arena_reserve(c, need)) return 1;
   HIPCK(c, hipEventRecord(c->ev0, c->st));
@@ -1160,7 +1237,37 @@ extern "C" int sacopt_get_costs(sacopt_ctx *c, int profile, int nframes, const s
   if (cost_round(c, pd, fr, chains, ncand, d_state, ch_costs)) return 1;
   memcpy(costs, ch_costs.data(), ch_costs.size() * 8);
   if (cost_state) HIPCK(c, hipMemcpyAsync(cost_state, d_state, (size_t)nframes * 8, hipMemcpyDeviceToHost, c->st));
-  return end_timing(c);
+  if (end_timing(c)) return 1;
+  // the residuals stay where they are until the next call: sacopt_recost_last can cost them again from another state
+  chain_bufs(pd, fr, chains, ncand, c->kept.bufs, c->kept.n);
+  c->kept.nframes = nframes; c->kept.ncand = ncand; c->kept.mark = c->used; c->kept.valid = true;
+  return 0;
+}
+
+// The candidates of the last sacopt_get_costs call, costed again from another CostGolomb start state: the cascade is not
+// re-run, the residuals never left the device. (Multi-GPU candidate split, SURVEY.md 8e: a rank first costs its slice from a
+// guessed state and later from the state its predecessor really ended with.)
+extern "C" int sacopt_recost_last(sacopt_ctx *c, double *costs, double *cost_state) {
+  if (!c) return 1;
+  HIPCK(c, hipSetDevice(c->device));
+  c->err.clear();
+  if (!c->kept.valid) { c->err = "sacopt_recost_last: no sacopt_get_costs call to re-cost (any other call on the context discards its residuals)"; return 1; }
+  if (!costs) { c->err = "bad arguments"; return 1; }
+  HIPCK(c, hipStreamSynchronize(c->st));
+  c->used = c->kept.mark;  // scratch of an earlier recost is reused
+  const int nframes = c->kept.nframes;
+  std::vector<double> st(nframes, 0.);
+  if (cost_state) st.assign(cost_state, cost_state + nframes);
+  double *d_state;
+  if (upload(c, st, &d_state)) return 1;
+  std::vector<double> ch_costs;
+  if (cost_round_bufs(c, nframes, c->kept.ncand, c->kept.bufs, c->kept.n, d_state, ch_costs)) return 1;
+  memcpy(costs, ch_costs.data(), ch_costs.size() * 8);
+  if (cost_state) {
+    HIPCK(c, hipMemcpyAsync(cost_state, d_state, (size_t)nframes * 8, hipMemcpyDeviceToHost, c->st));
+    HIPCK(c, hipStreamSynchronize(c->st));
+  }
+  return 0;
 }
 
 // candidate grids, generated exactly as the reference loop does (codec.cpp:392-404)
@@ -1185,7 +1292,7 @@ static size_t optimize_bytes(const ProfDesc &pd, int ncoef_loop, const std::vect
   for (int i = 0; i < ncoef_loop; i++)
     if (pd.nprefix[0] > i && grid[i].size() > lpc_jobs) lpc_jobs = grid[i].size();
   lpc_jobs += 1;  // the baseline chain rides along with the first round
-  return total_cand * (chain_bytes(pd, wn) + 8192 + sizeof(LpcJob)) + 32768 + lpc_jobs * (lpc_scratch_bytes(pd.type, wn) + 256);
+  return total_cand * (chain_bytes(pd, wn) + 8192 + sizeof(LpcJob)) + 32768 + lpc_jobs * (lpc_scratch_bytes(pd, wn) + 256);
 }
 
 // The search itself, on frames already staged (fr[f].from/n = optimisation window), all on c->st.
@@ -1260,6 +1367,7 @@ extern "C" int sacopt_optimize_frames(sacopt_ctx *c, int profile, int nframes, c
   if (nframes < 0 || (nframes && (!frames || !best))) { c->err = "bad arguments"; return 1; }
   if (ncoef_loop < 0 || ncoef_loop > pd.ncoef) { c->err = "ncoef_loop exceeds the profile's coefficient count (the reference would index past coefs[], codec.cpp:389)"; return 1; }
   if (!nframes) return 0;
+  if (check_frames(c, nframes, frames, nullptr, nullptr)) return 1;
   double prof[3 * SACOPT_MAX_COEFS];
   sacopt_base_profile(profile, prof);
   if (prof_in) memcpy(prof, prof_in, sizeof(double) * 3 * pd.ncoef);
@@ -1295,6 +1403,7 @@ extern "C" int sacopt_encode_frames(sacopt_ctx *c, int profile, int nframes, con
   if (nframes < 0 || (nframes && (!frames || !out || (ncoef_loop > 0 && !best)))) { c->err = "bad arguments"; return 1; }
   if (ncoef_loop < 0 || ncoef_loop > pd.ncoef) { c->err = "ncoef_loop exceeds the profile's coefficient count (the reference would index past coefs[], codec.cpp:389)"; return 1; }
   if (!nframes) return 0;
+  if (check_frames(c, nframes, frames, nullptr, nullptr)) return 1;
   double prof[3 * SACOPT_MAX_COEFS];
   sacopt_base_profile(profile, prof);
   if (prof_in) memcpy(prof, prof_in, sizeof(double) * 3 * pd.ncoef);
@@ -1304,8 +1413,7 @@ extern "C" int sacopt_encode_frames(sacopt_ctx *c, int profile, int nframes, con
   size_t need = 1 << 20;
   for (int f = 0; f < nframes; f++) {
     const int ns = frames[f].numsamples;
-    if (ns < 0) { c->err = "negative numsamples"; return 1; }
-    need += chain_bytes(pd, ns) + 2 * (((size_t)ns * 4 + 255) & ~(size_t)255) + 4096 + lpc_scratch_bytes(pd.type, ns) + sizeof(LpcJob) + 256 + pipe_bytes(ns) +
+    need += chain_bytes(pd, ns) + 2 * (((size_t)ns * 4 + 255) & ~(size_t)255) + 4096 + lpc_scratch_bytes(pd, ns) + sizeof(LpcJob) + 256 + pipe_bytes(ns) +
             ((out[f].map0 || out[f].map1) ? map_bytes(ns) : 0);
     if (ncoef_loop > 0) need += optimize_bytes(pd, ncoef_loop, grid, total_cand, ns / 8);
   }
@@ -1315,7 +1423,11 @@ extern "C" int sacopt_encode_frames(sacopt_ctx *c, int profile, int nframes, con
     sacopt_ctx *c; hipStream_t keep[5]; bool on;
     ~SetGuard() { if (on) { c->st = keep[0]; c->sB = keep[1]; c->sC = keep[2]; c->sD = keep[3]; c->sE = keep[4]; } }
   } set_guard{c, {c->st, c->sB, c->sC, c->sD, c->sE}, false};
-  if (c->split[0] && ncoef_loop > 0 && nframes <= 16 && pd.type == SACOPT_PROFILE_HIGH && !getenv("SACOPT_NOSPLIT")) {
+  bool use_split = c->split[0] && ncoef_loop > 0 && nframes <= 16 && pd.nlms == 4;
+#ifdef SACOPT_ABLATE
+  if (getenv("SACOPT_NOSPLIT")) use_split = false;
+#endif
+  if (use_split) {
     set_guard.on = true;
     c->st = c->split[0]; c->sB = c->split[1]; c->sC = c->split[2]; c->sD = c->split[3]; c->sE = c->split[4];
   }
@@ -1374,6 +1486,7 @@ extern "C" int sacopt_unpredict_stereo_frames(sacopt_ctx *c, int profile, int nf
   if (begin_call(c)) return 1;
   ProfDesc pd;
   if (!get_prof(profile, &pd)) { c->err = "unknown profile"; return 1; }
+  if (pd.ols_n != 24) { c->err = "the decoder-side cascade is built for the reference's profiles only (24-tap OLS stage)"; return 1; }
   if (nframes < 0 || (nframes && !frames)) { c->err = "bad arguments"; return 1; }
   if (!nframes) return 0;
   double base[3 * SACOPT_MAX_COEFS];
@@ -1406,7 +1519,7 @@ extern "C" int sacopt_unpredict_stereo_frames(sacopt_ctx *c, int profile, int nf
         build_unmap_table(used[k], tabs.back().data());
         uint32_t *dm = arena_alloc<uint32_t>(c, 2 * UN_MAPW);
         if (!dm) { c->err = "device arena exhausted"; return 1; }
-        HIPCK(c, hipMemcpyAsync(dm, tabs.back().data(), 2 * UN_MAPW * 4, hipMemcpyHostToDevice, c->st));
+        if (upload_bytes(c, dm, tabs.back().data(), 2 * UN_MAPW * 4, c->st)) return 1;
         j.map[k] = dm;
       }
       j.minval[k] = d.minval[k];
@@ -1513,31 +1626,36 @@ extern "C" int sacopt_lms_pair(sacopt_ctx *c, int S, int D, double mu1, double m
   HIPCK(c, hipEventCreate(&a));
   HIPCK(c, hipEventCreate(&b));
   HIPCK(c, hipEventRecord(a, c->st));
-  { const char *dbg = getenv("SACOPT_DBG"); int dm = dbg ? atoi(dbg) : 0;
-  if (sacopt_launch_lms(S, D, dj, 1, c->d_tab, c->bits | (dm << 8), c->st)) { c->err = "unsupported (S,D) or launch failure"; return 1; } }
+  int sw = 0;
+#ifdef SACOPT_ABLATE
+  if (const char *dbg = getenv("SACOPT_DBG")) sw = atoi(dbg) << 8;
+#endif
+  if (sacopt_launch_lms(S, D, dj, 1, c->d_tab, c->bits | sw, c->st)) { c->err = "unsupported (S,D) or launch failure"; return 1; }
   HIPCK(c, hipEventRecord(b, c->st));
   c->lms_ev.push_back({a, b});
   if (copy_out(c, p0, j.p[0], (size_t)n * 8) || copy_out(c, p1, j.p[1], (size_t)n * 8)) return 1;
   return end_timing(c);
 }
 
-extern "C" int sacopt_lpc3_pair(sacopt_ctx *c, double alpha, const int32_t *s0, const int32_t *s1, int n, double *p0, double *p1) {
+extern "C" int sacopt_lpc3_pair(sacopt_ctx *c, double alpha, int S, int D, const int32_t *s0, const int32_t *s1, int n, double *p0, double *p1) {
   if (!c) return 1;
   if (begin_call(c)) return 1;
   if (n < 0 || (n && (!s0 || !s1 || !p0 || !p1))) { c->err = "bad arguments"; return 1; }
+  ProfDesc pd;
+  if (!((S == 16 || S == 24) && D == 8) || !get_prof(S == 16 ? SACOPT_PROFILE_HIGH : SACOPT_PROFILE_HIGH32, &pd)) { c->err = "unsupported (S,D): (16,8) and (24,8) are built"; return 1; }
   if (!n) return 0;
-  if (arena_reserve(c, (size_t)n * 8 * 6 + lpc_scratch_bytes(SACOPT_PROFILE_HIGH, n) + (1 << 16))) return 1;
+  if (arena_reserve(c, (size_t)n * 8 * 6 + lpc_scratch_bytes(pd, n) + (1 << 16))) return 1;
   HIPCK(c, hipEventRecord(c->ev0, c->st));
   LpcJob j;
   memset(&j, 0, sizeof(j));
   if (to_dev(c, s0, n, &j.s[0]) || to_dev(c, s1, n, &j.s[1])) return 1;
   for (int k = 0; k < 2; k++) { j.p[k] = arena_alloc<double>(c, n); j.x1[k] = arena_alloc<double>(c, n); }
   j.alpha = alpha; j.n = n;
-  if (lpc_scratch_alloc(c, SACOPT_PROFILE_HIGH, j)) return 1;
+  if (lpc_scratch_alloc(c, pd, j)) return 1;
   std::vector<LpcJob> jobs = {j};
   LpcJob *dj;
   if (upload(c, jobs, &dj)) return 1;
-  if (sacopt_launch_lpc3(dj, 1, n, c->st)) { c->err = "LPC3 launch failed"; return 1; }
+  if (sacopt_launch_lpc3(dj, 1, n, pd.ols_n, c->st)) { c->err = "LPC3 launch failed"; return 1; }
   if (copy_out(c, p0, j.p[0], (size_t)n * 8) || copy_out(c, p1, j.p[1], (size_t)n * 8)) return 1;
   return end_timing(c);
 }

@@ -29,8 +29,9 @@ __device__ __forceinline__ int kth_set_bit(uint32_t x, int k) {
 // Remap::Unmap(pred, merr) (map.cpp:154-168) for a whole wave (arguments and result uniform). mp: LDS, UN_MAPW bitmap
 // words over the values -32768..32768 (bit v+32768; value 0 always set, map.cpp:138) then UN_MAPW counts of set bits
 // in the words before each word (entry 2049 = total). The reference walks err = 1, 2, ... until `merr` used values
-// have been passed: that is a select of the (rank + merr)-th set bit. A stream that asks for more used values than
-// exist makes the reference loop forever; here it returns +-(4*32768 + 1), as the oracle does.
+// have been passed: that is a select of the (rank + merr)-th set bit, at whatever distance it lies (a garbage prediction far
+// outside the table still terminates in the reference, with the true distance). A stream that asks for more used values
+// than exist in that direction makes the reference loop forever; only then the result is +-(4*32768 + 1), as in the oracle.
 __device__ __forceinline__ int unmap_wave(const uint32_t *mp, int pred, int merr, int lane) {
   if (merr == 0) return 0;
   const uint32_t *bw = mp, *rk = mp + UN_MAPW;
@@ -63,8 +64,7 @@ __device__ __forceinline__ int unmap_wave(const uint32_t *mp, int pred, int merr
   }
   w = __builtin_amdgcn_readfirstlane(w);
   const long long x = 32ll * w + kth_set_bit(bw[w], kglob - (int)rk[w]);
-  long long d = sgn > 0 ? x - ip : ip - x;  // the oracle stops walking after 4*32768 + 1 steps
-  if (d > 4 * 32768 + 1) d = 4 * 32768 + 1;
+  const long long d = sgn > 0 ? x - ip : ip - x;  // |pred| < 2^31 and x in 0..65536: fits int32 after the sign
   return (int)(sgn * d);
 }
 

@@ -47,29 +47,34 @@ def gather_frame_rows(local_rows: np.ndarray, nframes: int, world: int, rank: in
 # One frame's candidate population across GPUs (BASELINE config 5)
 # ---------------------------------------------------------------------------------------------
 class SacoptEvaluator:
-    """What optimize_split needs from a device: residuals of candidate parameter sets over a window
-    (FrameCoder::PredictStereoFrame, src/codec.cpp:154-214) and CostGolomb::Calc with its carried running
-    mean (src/codec.cpp:315-339), both through the C ABI of libsacopt."""
+    """What optimize_split needs from a device, both through the C ABI of libsacopt:
+      get_costs  FrameCoder::GetCost for a slice of candidates (src/codec.cpp:341-352), CostGolomb mean carried in call order;
+      recost     the same slice costed again from another start state (sacopt_recost_last): the cascade is not re-run and
+                 the residuals never leave the GPU.
+    frames: (s0, s1) numpy arrays or (dev_ptr0, dev_ptr1, numsamples)."""
 
     def __init__(self, ctx):
         self.ctx = ctx
+        self._shape = None
 
-    def window_residuals(self, profile, frames, start, n, coefs):
-        """frames: list of (s0, s1); coefs[f]: [k, ncoef] -> out[f][c] = (e0, e1) of candidate c of frame f."""
-        k = len(coefs[0]) if coefs else 0
-        if k == 0:
-            return [[] for _ in frames]
-        flat = [fr for fr in frames for _ in range(k)]
-        res = self.ctx.predict(profile, flat, frm=[s for s in start for _ in range(k)], n=[m for m in n for _ in range(k)],
-                               coefs=np.concatenate([np.asarray(c, np.float64).reshape(k, -1) for c in coefs]))
-        return [[(res[f * k + c]["e0"], res[f * k + c]["e1"]) for c in range(k)] for f in range(len(frames))]
+    def get_costs(self, profile, frames, start, n, coefs, state):
+        """coefs[f]: [k, ncoef]. Returns (costs[k, nframes], end state[nframes])."""
+        cc = np.stack([np.asarray(c, np.float64) for c in coefs])
+        costs, st = self.ctx.get_costs(profile, frames, cc, frm=start, n=n, state=state)
+        self._shape = cc.shape[:2]
+        return costs.T.copy(), st
 
-    def cost_golomb(self, buf, state):
-        return self.ctx.cost_golomb(buf, state)
+    def recost(self, state):
+        costs, st = self.ctx.recost_last(self._shape[0], self._shape[1], state)
+        return costs.T.copy(), st
 
 
 def _gather_rows(local, nrows, world, rank, group):
     return gather_frame_rows(np.asarray(local, np.float64).reshape(-1, np.asarray(local).shape[-1]), nrows, world, rank, group)
+
+
+def _numsamples(fr):
+    return int(fr[2]) if len(fr) > 2 else len(fr[0])
 
 
 def optimize_split(ev, profile, frames, prof, ncoef_loop, world=1, rank=0, group=None, stats=None):
@@ -78,12 +83,16 @@ def optimize_split(ev, profile, frames, prof, ncoef_loop, world=1, rank=0, group
     Each rank evaluates a contiguous slice of the round's candidates (for all `frames`, same profile table `prof` =
     ncoef x {vmin, vmax, vdef}); costs are all-gathered and every rank takes the same argmin with the reference's strict
     `<` in call order (lowest index wins ties, codec.cpp:399). The one CostGolomb instance of an Optimize call carries its
-    running mean from candidate to candidate (codec.cpp:364), i.e. across ranks. It forgets its start (0.98^n), so each
-    rank first publishes the mean its LAST candidate ends with when started from 0 (a guess), every rank starts its slice
-    from its predecessor's guess and carries the true mean inside the slice, and the guess is checked against the mean
-    the predecessor actually ended with: all equal => exact by induction from rank 0, whose start is the true carried
-    state. Any mismatch (short windows) => the slices are re-costed rank after rank from the true state (broadcasts).
-    stats (optional dict) counts rounds whose guesses verified / that needed the chain.
+    running mean from candidate to candidate (codec.cpp:364), i.e. across ranks. It forgets its start (0.98^n), so:
+      pass 1  every rank costs its slice from 0 (rank 0: from the true carried state); the mean it ends with is the GUESS
+              its successor starts from -- one all-gather of nframes doubles per rank;
+      pass 2  every rank costs its slice again from its predecessor's guess (ev.recost: residuals stay on the GPU) and
+              reports whether it still ends where pass 1 ended; if every rank whose end feeds a successor does, all costs
+              are exact by induction from rank 0 -- one all-gather of the costs + end states + flags;
+      else    (windows shorter than ~4k samples) the slices are re-costed rank after rank from the true state, one
+              broadcast each. Exact in every case; the guesses only save time.
+    Collectives run on device tensors when the backend is nccl (RCCL). stats (optional dict) counts rounds whose guesses
+    verified / that needed the chain.
     Returns (best[nframes, ncoef], traces: per frame rows {coef (-1 = baseline call), x, cost} in call order)."""
     import torch
     import torch.distributed as dist
@@ -92,8 +101,8 @@ def optimize_split(ev, profile, frames, prof, ncoef_loop, world=1, rank=0, group
     if ncoef_loop > ncoef:
         raise ValueError("ncoef_loop exceeds the profile's coefficient count")
     cur = np.tile(prof[:, 2], (nf, 1))            # profile.coefs[i].vdef per frame
-    wn = [len(fr[0]) // 8 for fr in frames]       # codec.cpp:356-359
-    st = [(len(fr[0]) - w) // 2 for fr, w in zip(frames, wn)]
+    wn = [_numsamples(fr) // 8 for fr in frames]  # codec.cpp:356-359
+    st = [(_numsamples(fr) - w) // 2 for fr, w in zip(frames, wn)]
     state = np.zeros(nf)                          # CostGolomb::mean_err, one instance per Optimize call
     best_cost = np.zeros(nf)
     traces = [[] for _ in range(nf)]
@@ -110,41 +119,35 @@ def optimize_split(ev, profile, frames, prof, ncoef_loop, world=1, rank=0, group
         nc = len(cands)
         lo, hi = frame_shard(nc, world, rank)
         mine = cands[lo:hi]
+        k = len(mine)
         coefs = []
         for f in range(nf):
-            cf = np.tile(cur[f], (len(mine), 1))
+            cf = np.tile(cur[f], (k, 1))
             for c, (ci, x) in enumerate(mine):
                 cf[c, max(ci, 0)] = x
             coefs.append(cf)
-        res = ev.window_residuals(profile, frames, st, wn, coefs)
-
-        def cost_slice(start_state):
-            costs, s = np.zeros((len(mine), nf)), np.array(start_state, np.float64)
-            for f in range(nf):
-                for c in range(len(mine)):
-                    c1, s[f] = ev.cost_golomb(res[f][c][0], s[f])   # GetCost, codec.cpp:349-351
-                    c2, s[f] = ev.cost_golomb(res[f][c][1], s[f])
-                    costs[c, f] = (c1 + c2) / 2.
-            return costs, s
-
         if world == 1:
-            costs, state = cost_slice(state)
+            costs, state = ev.get_costs(profile, frames, st, wn, coefs, state)
         else:
-            # pass 1: the mean my last candidate ends with, started from 0
-            guess = np.zeros((1, nf))
-            if mine:
-                for f in range(nf):
-                    _, g = ev.cost_golomb(res[f][-1][0], 0.0)
-                    _, guess[0, f] = ev.cost_golomb(res[f][-1][1], g)
-            guesses = _gather_rows(guess, world, world, rank, group)
-            # pass 2: my slice from my predecessor's guess (rank 0: the true carried state)
-            my_costs, my_end = cost_slice(state if rank == 0 else guesses[rank - 1])
-            ok = 1.0 if (not mine or my_end.tobytes() == guesses[rank].tobytes()) else 0.0
-            tail = _gather_rows(np.concatenate([my_end, [ok]])[None, :], world, world, rank, group)
+            # pass 1
+            c1, e1 = (ev.get_costs(profile, frames, st, wn, coefs, state if rank == 0 else np.zeros(nf))
+                      if k else (np.zeros((0, nf)), np.zeros(nf)))
+            guesses = _gather_rows(e1[None, :], world, world, rank, group)
+            # pass 2
+            c2, e2 = (c1, e1) if (rank == 0 or not k) else ev.recost(guesses[rank - 1])
+            ok = 1.0 if e2.tobytes() == e1.tobytes() else 0.0
+            per = (nc + world - 1) // world
+            blk = np.zeros((per + 1, nf + 1))
+            blk[:k, :nf] = c2
+            blk[per, :nf], blk[per, nf] = e2, ok
+            allb = _gather_rows(blk, world * (per + 1), world, rank, group).reshape(world, per + 1, nf + 1)
             active = min(world, nc)               # ranks with a non-empty slice (empty ones are trailing)
-            if all(tail[r, nf] == 1.0 for r in range(active - 1)):   # the last slice's guess feeds nobody
-                costs = _gather_rows(my_costs if mine else np.zeros((0, nf)), nc, world, rank, group)
-                state = tail[active - 1, :nf].copy()
+            if all(allb[r, per, nf] == 1.0 for r in range(active - 1)):   # the last slice's end feeds nobody
+                costs = np.zeros((nc, nf))
+                for r in range(active):
+                    l, h = frame_shard(nc, world, r)
+                    costs[l:h] = allb[r, :h - l, :nf]
+                state = allb[active - 1, per, :nf].copy()
                 if stats is not None:
                     stats["verified"] = stats.get("verified", 0) + 1
             else:
@@ -155,7 +158,7 @@ def optimize_split(ev, profile, frames, prof, ncoef_loop, world=1, rank=0, group
                     l, h = frame_shard(nc, world, r)
                     buf = torch.zeros((h - l + 1, nf), dtype=torch.float64)
                     if rank == r:
-                        c_r, e_r = cost_slice(state)
+                        c_r, e_r = ev.recost(state)
                         buf = torch.from_numpy(np.concatenate([c_r, e_r[None, :]]))
                     buf = buf.to(dev)
                     dist.broadcast(buf, src=r if group is None else dist.get_global_rank(group, r), group=group)

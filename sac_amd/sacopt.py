@@ -4,16 +4,18 @@ The library is the product; this module only marshals numpy arrays / raw device 
 the C ABI. There is no fallback: if libsacopt.so is missing or no gfx950 GPU is usable, loading
 or `Context()` raises.
 """
+import atexit
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SACOPT_LIB") or os.path.join(_HERE, "libsacopt.so")  # SACOPT_LIB: instrumented builds of tools/ only
 
-PROFILE_FAST, PROFILE_NORMAL, PROFILE_HIGH = 0, 1, 2
-NCOEF = {0: 1, 1: 6, 2: 8}
+PROFILE_FAST, PROFILE_NORMAL, PROFILE_HIGH, PROFILE_HIGH32 = 0, 1, 2, 3
+NCOEF = {0: 1, 1: 6, 2: 8, 3: 8}
 
 
 class Frame(C.Structure):
@@ -50,6 +52,7 @@ def lib():
                                                    C.c_void_p, C.c_void_p]
         L.sacopt_get_costs.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                        C.c_void_p, C.c_void_p, C.c_void_p]
+        L.sacopt_recost_last.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.sacopt_optimize_frames.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                              C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.sacopt_encode_frames.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
@@ -58,7 +61,7 @@ def lib():
         L.sacopt_cost_meanrms.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.sacopt_lms_pair.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p,
                                       C.c_int, C.c_void_p, C.c_void_p]
-        L.sacopt_lpc3_pair.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.sacopt_lpc3_pair.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.sacopt_rls_run.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.sacopt_last_timing.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
@@ -66,7 +69,7 @@ def lib():
 
 
 EXPORTS = ["sacopt_create", "sacopt_destroy", "sacopt_last_error", "sacopt_probe_rsqrt", "sacopt_base_profile",
-           "sacopt_predict_stereo_frames", "sacopt_get_costs", "sacopt_optimize_frames", "sacopt_encode_frames", "sacopt_unpredict_stereo_frames", "sacopt_cost_golomb",
+           "sacopt_predict_stereo_frames", "sacopt_get_costs", "sacopt_recost_last", "sacopt_optimize_frames", "sacopt_encode_frames", "sacopt_unpredict_stereo_frames", "sacopt_cost_golomb",
            "sacopt_cost_meanrms", "sacopt_lms_pair", "sacopt_lpc3_pair", "sacopt_rls_run", "sacopt_last_timing"]
 
 
@@ -97,8 +100,23 @@ class SacoptError(RuntimeError):
     pass
 
 
+_live = weakref.WeakSet()   # contexts not yet closed
+_finalizing = False
+
+
+@atexit.register
+def _close_live_contexts():
+    """A context owns CU-masked streams, events and device memory: it has to go while the HIP runtime (and a profiler
+    tool attached to it) is still alive, i.e. before interpreter teardown -- a sacopt_destroy from __del__ during
+    finalisation ran after the runtime's own exit handlers and crashed in __cxa_finalize under rocprofv3."""
+    global _finalizing
+    for c in list(_live):
+        c.close()
+    _finalizing = True
+
+
 class Context:
-    """One per GPU. rsqrt_tab=None probes the CPU this process runs on."""
+    """One per GPU. rsqrt_tab=None probes the CPU this process runs on. Use as a context manager or call close()."""
 
     def __init__(self, device=0, rsqrt_tab=None, rsqrt_bits=0):
         self._h = C.c_void_p()
@@ -106,15 +124,26 @@ class Context:
         rc = lib().sacopt_create(device, _p(tab), rsqrt_bits, C.byref(self._h))
         if rc:
             raise SacoptError(lib().sacopt_last_error(None).decode())
+        _live.add(self)
 
     def close(self):
-        if self._h:
+        if self._h and not _finalizing:
             lib().sacopt_destroy(self._h)
-            self._h = C.c_void_p()
+        self._h = C.c_void_p()
+        _live.discard(self)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
 
     def __del__(self):
+        # once interpreter finalisation has begun the handle is abandoned (the process is going away)
         try:
-            self.close()
+            if not _finalizing:
+                self.close()
         except Exception:
             pass
 
@@ -187,6 +216,13 @@ class Context:
         costs = np.zeros((nf, ncand))
         st = np.zeros(nf) if state is None else np.ascontiguousarray(state, dtype=np.float64).copy()
         self._ck(lib().sacopt_get_costs(self._h, profile, nf, arr, _p(frm_a), _p(n_a), ncand, _p(cc), _p(costs), _p(st)))
+        return costs, st
+
+    def recost_last(self, nframes, ncand, state=None):
+        """sacopt_recost_last: the candidates of the last get_costs call from another start state."""
+        costs = np.zeros((nframes, ncand))
+        st = np.zeros(nframes) if state is None else np.ascontiguousarray(state, dtype=np.float64).copy()
+        self._ck(lib().sacopt_recost_last(self._h, _p(costs), _p(st)))
         return costs, st
 
     def optimize(self, profile, frames, prof=None, ncoef_loop=None, max_rows=128):
@@ -278,10 +314,10 @@ class Context:
         self._ck(lib().sacopt_lms_pair(self._h, S, D, mu1, mu2, _p(x0), _p(x1), len(x0), _p(p0), _p(p1)))
         return p0, p1
 
-    def lpc3_pair(self, alpha, s0, s1):
+    def lpc3_pair(self, alpha, s0, s1, S=16, D=8):
         s0 = np.ascontiguousarray(s0, dtype=np.int32); s1 = np.ascontiguousarray(s1, dtype=np.int32)
         p0 = np.zeros(len(s0)); p1 = np.zeros(len(s0))
-        self._ck(lib().sacopt_lpc3_pair(self._h, alpha, _p(s0), _p(s1), len(s0), _p(p0), _p(p1)))
+        self._ck(lib().sacopt_lpc3_pair(self._h, alpha, S, D, _p(s0), _p(s1), len(s0), _p(p0), _p(p1)))
         return p0, p1
 
     def rls_run(self, nst, alpha, pv, val):

@@ -132,5 +132,61 @@ def main_unpredict():
     print("wrote", len(out), "arrays")
 
 
+def main_config5():
+    """tests/golden/golden_config5.npz: BASELINE configs[4]'s shape -- 24-bit 96 kHz, framesize 384000 (optimizer window
+    48000), stereo pairs of an 8-channel frame treated as frames.
+      * r_*  : the REAL reference (24-tap OLS as shipped): FrameCoder::Optimize trace + winners of pair 0, SHA-256 of its
+               full-frame residuals (the reference handles any int32 sample in PredictStereoFrame; only its CLI / WAV
+               reader / Remap table are 16-bit);
+      * lpc32: LPC3(0.997, 24, 8, 8, 500) stage outputs from the REAL reference class (lpc.h:181 takes S and D);
+      * o32_*: profile 3 (StereoHigh with that 32-tap stage) from the ORACLE -- no reference profile has this shape, so
+               these rows are "parity unpinned" (GPU vs restatement only).
+    About 5 minutes of CPU."""
+    import hashlib
+    from concurrent.futures import ProcessPoolExecutor
+    out = {}
+    n = 384000
+    sha = lambda a: np.frombuffer(hashlib.sha256(np.ascontiguousarray(a, dtype=np.int32).tobytes()).digest(), np.uint8)
+    out["seeds"] = np.array([320, 321, 322, 323], np.int32)
+    with ProcessPoolExecutor(3) as ex:
+        f_ref = ex.submit(_c5_ref, n)
+        f_o32 = ex.submit(_c5_o32, n)
+        f_o32s = ex.submit(_c5_o32_small)
+        out.update(f_ref.result()); out.update(f_o32.result()); out.update(f_o32s.result())
+    ref = Ref()
+    L, R = stereo_clip(11, 6000)
+    out["lpc32_p0"], out["lpc32_p1"] = ref.lpc3_pair(0.997, L[:3000], R[:3000], S=24, D=8)
+    np.savez_compressed(os.path.join(HERE, "golden_config5.npz"), **out)
+    print("wrote", len(out), "arrays")
+
+
+def _sha(a):
+    import hashlib
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a, dtype=np.int32).tobytes()).digest(), np.uint8)
+
+
+def _c5_ref(n):
+    ref = Ref()
+    L, R = stereo_clip(320, n, rate=96000, bits=24)
+    best, trace = ref.optimize_trace(2, L, R)
+    d = ref.predict(2, L, R, maps=True)
+    return {"r_best": best, "r_trace": trace, "r_e0_sha": _sha(d["e0"]), "r_e1_sha": _sha(d["e1"]), "r_maxbpn": d["maxbpn"][:2].copy()}
+
+
+def _c5_o32(n):
+    orc = Oracle()   # native rsqrtss of this (Intel) host == the fixture table (checked by main())
+    L, R = stereo_clip(321, n, rate=96000, bits=24)
+    best, trace = orc.optimize(3, L, R)
+    return {"o32_best": best, "o32_trace": trace}
+
+
+def _c5_o32_small():
+    orc = Oracle()
+    L, R = stereo_clip(11, 6000)
+    d = orc.predict(3, L, R, frm=0, n=4096)
+    best, trace = orc.optimize(3, *stereo_clip(12, 8192))
+    return {"o32_e0": d["e0"], "o32_e1": d["e1"], "o32s_best": best, "o32s_trace": trace}
+
+
 if __name__ == "__main__":
-    main_unpredict() if sys.argv[1:] == ["unpredict"] else main()
+    {"unpredict": main_unpredict, "config5": main_config5}.get((sys.argv[1:] or [""])[0], main)()

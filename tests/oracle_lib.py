@@ -96,11 +96,11 @@ class _Lib:
                                                  _ptr(x0), _ptr(x1), C.c_int(n), _ptr(p0), _ptr(p1))
         return p0, p1
 
-    def lpc3_pair(self, alpha, s0, s1):
+    def lpc3_pair(self, alpha, s0, s1, S=16, D=8):
         s0 = np.ascontiguousarray(s0, dtype=np.int32); s1 = np.ascontiguousarray(s1, dtype=np.int32)
         n = len(s0)
         p0 = np.zeros(n); p1 = np.zeros(n)
-        getattr(self.lib, self.pre + "lpc3_pair")(C.c_double(alpha), _ptr(s0), _ptr(s1), C.c_int(n), _ptr(p0), _ptr(p1))
+        getattr(self.lib, self.pre + "lpc3_pair")(C.c_double(alpha), C.c_int(S), C.c_int(D), _ptr(s0), _ptr(s1), C.c_int(n), _ptr(p0), _ptr(p1))
         return p0, p1
 
     def rls_run(self, n, alpha, pv, val):
@@ -113,7 +113,7 @@ class _Lib:
     def cascade_trace(self, profile, s0, s1, coefs=None):
         s0 = np.ascontiguousarray(s0, dtype=np.int32); s1 = np.ascontiguousarray(s1, dtype=np.int32)
         n = len(s0)
-        nst = 5 if profile == 2 else 4
+        nst = 5 if profile >= 2 else 4
         p = np.zeros((n, 2, nst)); v = np.zeros((n, 2, nst))
         e0 = np.zeros(n, np.int32); e1 = np.zeros(n, np.int32)
         cf = None if coefs is None else np.ascontiguousarray(coefs, dtype=np.float64)
@@ -236,6 +236,32 @@ def ref_encode_residuals(ref, profile, s0, s1, res):
     a = [np.ascontiguousarray(res[k], dtype=np.int32) for k in ("u0", "u1", "m0", "m1", "maxbpn")]
     return _ref_encode(ref, ref.lib.ref_encode_residuals, C.c_int(profile), _ptr(s0), _ptr(s1), C.c_int(len(s0)),
                        *[_ptr(x) for x in a], total=len(s0))
+
+
+def ref_encode_channels(ref, profile, s0, s1, res):
+    """The reference's Encode() (both coders per channel, smaller kept: codec.cpp:268-280) fed with residuals computed
+    elsewhere: [(payload bytes, enc_mapped, flag bits)] x 2 -- what a host-side container writer packs."""
+    s0 = np.ascontiguousarray(s0, dtype=np.int32); s1 = np.ascontiguousarray(s1, dtype=np.int32)
+    a = [np.ascontiguousarray(res[k], dtype=np.int32) for k in ("u0", "u1", "m0", "m1", "maxbpn")]
+    cap = 16 * len(s0) + 4096
+    out = np.zeros(cap, np.uint8)
+    info = np.zeros(6, np.int32)
+    n = ref.lib.ref_encode_channels(C.c_int(profile), _ptr(s0), _ptr(s1), C.c_int(len(s0)), *[_ptr(x) for x in a], _ptr(out),
+                                    C.c_int(cap), _ptr(info))
+    assert n >= 0
+    l0, l1 = int(info[0]), int(info[3])
+    return [(out[:l0].tobytes(), bool(info[1]), int(info[2])), (out[l0:l0 + l1].tobytes(), bool(info[4]), int(info[5]))]
+
+
+def ref_decode_channels(ref, profile, n, ch0, ch1):
+    """The reference's Decode(): payloads -> (e0, e1, used0 | None, used1 | None)."""
+    b = [np.frombuffer(c[0], np.uint8) if len(c[0]) else np.zeros(1, np.uint8) for c in (ch0, ch1)]
+    e0 = np.zeros(n, np.int32); e1 = np.zeros(n, np.int32)
+    used = [np.zeros(2 * 32769, np.uint8) for _ in range(2)]
+    ref.lib.ref_decode_channels(C.c_int(profile), C.c_int(n), _ptr(b[0]), C.c_int(len(ch0[0])), C.c_int(int(ch0[1])), C.c_int(ch0[2]),
+                                _ptr(b[1]), C.c_int(len(ch1[0])), C.c_int(int(ch1[1])), C.c_int(ch1[2]), _ptr(e0), _ptr(e1),
+                                _ptr(used[0]), _ptr(used[1]))
+    return e0, e1, (used[0] if ch0[1] else None), (used[1] if ch1[1] else None)
 
 
 def have_ref():

@@ -41,3 +41,11 @@ def test_no_gpu_fails_loudly():
         pytest.skip("GPU present")
     with pytest.raises(sacopt.SacoptError):
         sacopt.Context(0)
+
+
+def test_product_library_has_no_debug_switches():
+    # A/B and ablation switches (some of them break exactness) exist only in -DSACOPT_ABLATE builds of tools/:
+    # the product library must not even contain the names of the environment variables that select them
+    blob = open(sacopt.LIB_PATH, "rb").read()
+    for name in (b"SACOPT_DBG", b"SACOPT_NOSPLIT"):
+        assert name not in blob, name

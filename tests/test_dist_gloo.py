@@ -80,15 +80,22 @@ class _OracleEvaluator:
         self.o = Oracle()
         self.o.set_rsqrt_table(d["tab"].astype(np.float32), int(d["bits"]))
 
-    def window_residuals(self, profile, frames, start, n, coefs):
-        out = []
+    def get_costs(self, profile, frames, start, n, coefs, state):
+        # the evaluator interface of sac_amd.dist.SacoptEvaluator: residuals of the slice are kept for recost()
+        self.res = []
         for (s0, s1), a, m, cf in zip(frames, start, n, coefs):
-            rs = [self.o.predict(profile, s0, s1, frm=a, n=m, coefs=c) for c in cf]
-            out.append([(r["e0"], r["e1"]) for r in rs])
-        return out
+            self.res.append([self.o.predict(profile, s0, s1, frm=a, n=m, coefs=c) for c in cf])
+        return self.recost(state)
 
-    def cost_golomb(self, buf, state):
-        return self.o.cost_golomb(buf, state)
+    def recost(self, state):
+        k, nf = len(self.res[0]), len(self.res)
+        costs, st = np.zeros((k, nf)), np.array(state, np.float64)
+        for f in range(nf):
+            for c in range(k):
+                c1, st[f] = self.o.cost_golomb(self.res[f][c]["e0"], st[f])   # GetCost, codec.cpp:349-351
+                c2, st[f] = self.o.cost_golomb(self.res[f][c]["e1"], st[f])
+                costs[c, f] = (c1 + c2) / 2.
+        return costs, st
 
 
 def _split_worker(rank, world, port, profile, lens, ncoef_loop, q):
@@ -108,14 +115,16 @@ def _split_worker(rank, world, port, profile, lens, ncoef_loop, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("profile,lens,ncoef_loop", [
-    (2, [4000], 8),           # 500-sample window: the running mean has not forgotten its start -> guesses fail, rank chain
-    (1, [34000, 33000], 6),   # >= 4125-sample windows: guesses verify, costs gathered in one collective; two frames
-    (0, [2000], 1),           # one coefficient: round 0 = baseline + 11 candidates
+@pytest.mark.parametrize("world,profile,lens,ncoef_loop", [
+    (3, 2, [640], 8),            # 80-sample window: a slice is too short for the running mean to forget its start -> the
+                                 # middle rank's guess fails, slices re-costed rank after rank (with 2 ranks nothing is ever
+                                 # guessed: rank 0 starts from the true state and its end is rank 1's true start)
+    (3, 1, [34000, 33000], 6),   # >= 4125-sample windows: guesses verify, costs gathered in one collective; two frames
+    (2, 1, [9000], 6),
+    (2, 0, [2000], 1),           # one coefficient: round 0 = baseline + 11 candidates
 ])
-def test_two_rank_candidate_split(oracle, profile, lens, ncoef_loop):
+def test_candidate_split_over_ranks(oracle, world, profile, lens, ncoef_loop):
     from sac_amd.synth import stereo_clip
-    world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -134,7 +143,7 @@ def test_two_rank_candidate_split(oracle, profile, lens, ncoef_loop):
             assert best[k].tobytes() == want_best[:len(best[k])].tobytes(), (rank, k)
     for rank, best, traces, stats in got:  # both mechanisms are exercised: short windows chain, long ones verify
         assert stats.get("chained", 0) + stats.get("verified", 0) == ncoef_loop
-        if max(lens) <= 4000:
+        if max(lens) <= 1000:
             assert stats.get("chained", 0) > 0
         else:
             assert stats.get("verified", 0) == ncoef_loop

@@ -1,5 +1,5 @@
-"""GPU: one frame's candidate population split over two ranks, both ranks on this box's one GPU (own
-process and sacopt context each, gloo for the collectives): sac_amd.dist.optimize_split through the C ABI must give
+"""GPU: one frame's candidate population split over two or three ranks, all ranks on this box's one GPU (own
+process and sacopt context each, gloo for the collectives; residuals stay on the device: sacopt_get_costs + sacopt_recost_last): sac_amd.dist.optimize_split through the C ABI must give
 the rows of the library's single-GPU sacopt_optimize_frames, bit for bit."""
 import os
 import socket
@@ -10,7 +10,12 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, profile, lens, q):
+def _clips(lens, bits):
+    from sac_amd.synth import stereo_clip
+    return [stereo_clip(50 + k, n, rate=96000 if bits == 24 else 44100, bits=bits) for k, n in enumerate(lens)]
+
+
+def _worker(rank, world, port, profile, lens, bits, q):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -20,7 +25,7 @@ def _worker(rank, world, port, profile, lens, q):
     from sac_amd.synth import stereo_clip
     d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rsqrt_table.npz"))
     ctx = sacopt.Context(0, d["tab"].astype(np.float32), int(d["bits"]))
-    frames = [stereo_clip(50 + k, n) for k, n in enumerate(lens)]
+    frames = _clips(lens, bits)
     stats = {}
     best, traces = optimize_split(SacoptEvaluator(ctx), profile, frames, sacopt.base_profile(profile), sacopt.NCOEF[profile],
                                   world, rank, stats=stats)
@@ -30,23 +35,27 @@ def _worker(rank, world, port, profile, lens, q):
     ctx.close()
 
 
-@pytest.mark.parametrize("profile,lens", [(2, [40000, 6000]), (1, [36000])])
-def test_candidate_split_two_ranks_one_gpu(rsqrt_table, profile, lens):
+@pytest.mark.parametrize("world,profile,lens,bits", [
+    (2, 2, [40000, 6000], 16), (2, 1, [36000], 16),
+    (3, 2, [30000, 900], 16),       # three ranks: the middle slice starts from a guessed state (verified / chained per frame length)
+    (2, 2, [384000, 384000], 24),   # BASELINE configs[4]'s frame: two 24-bit 96 kHz pairs, 48000-sample windows
+    (2, 3, [384000], 24),           # ... with the 32-tap OLS stage
+])
+def test_candidate_split_ranks_one_gpu(rsqrt_table, world, profile, lens, bits):
     import torch.multiprocessing as mp
     from sac_amd import sacopt
-    from sac_amd.synth import stereo_clip
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     mctx = mp.get_context("spawn")
     q = mctx.Queue()
-    procs = [mctx.Process(target=_worker, args=(r, 2, port, profile, lens, q)) for r in range(2)]
+    procs = [mctx.Process(target=_worker, args=(r, world, port, profile, lens, bits, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = [q.get(timeout=300) for _ in range(2)]
+    got = [q.get(timeout=300) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     ctx = sacopt.Context(0, *rsqrt_table)
-    frames = [stereo_clip(50 + k, n) for k, n in enumerate(lens)]
+    frames = _clips(lens, bits)
     best, traces, _ = ctx.optimize(profile, frames)
     ctx.close()
     for rank, b, t, stats in got:

@@ -1,0 +1,161 @@
+"""GPU: stream level. (1) Whole .sac files: FrameCoder::Predict on the GPU (through the C ABI) + the reference's own
+bit-plane coder (oracle/_ref, test-only) + this repo's container writer (sac_amd/host/sacfile.h) must give the files
+the reference's program wrote (tests/golden/sacfiles.npz). (2) BASELINE configs[4]'s shape: optimizer on 24-bit 96 kHz
+384000-sample pairs against rows generated from the real reference; the 32-tap OLS variant against the oracle
+("parity unpinned": no reference profile has that shape). (3) The opt-in stream extension that carries the optimiser's
+parameters: encode -> file -> decode round trip."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib
+from sac_amd import sacfile, sacopt
+from sac_amd.synth import stereo_clip
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def same_bits(a, b):
+    a = np.ascontiguousarray(a); b = np.ascontiguousarray(b)
+    return a.shape == b.shape and a.tobytes() == b.tobytes()
+
+
+@pytest.fixture(scope="module")
+def ctx(rsqrt_table):
+    c = sacopt.Context(0, *rsqrt_table)   # the fixtures were written on an Intel host: its rsqrtss table
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def sacfiles():
+    return dict(np.load(os.path.join(HERE, "golden", "sacfiles.npz"), allow_pickle=False))
+
+
+@pytest.fixture(scope="module")
+def c5():
+    return dict(np.load(os.path.join(HERE, "golden", "golden_config5.npz"), allow_pickle=False))
+
+
+def gpu_sac_file(ctx, ref, seed, rate, n, prof, optimize):
+    """Codec::EncodeFile (codec.cpp:530-556): all frames of the file in ONE library call."""
+    L, R = stereo_clip(seed, n, rate=rate)
+    fs = 4 * rate
+    frames = [(L[a:a + fs], R[a:a + fs]) for a in range(0, n, fs)]
+    best, outs = ctx.encode(prof, frames, ncoef_loop=(None if optimize else 0), maps=True)
+    blob = sacfile.write_header(2, rate, 16, n, prof, sacfile.canonical_wav_metadata(2, rate, 16, n))
+    for (l, r), o in zip(frames, outs):
+        ch = oracle_lib.ref_encode_channels(ref, prof, l, r, o)
+        blob += sacfile.write_frame(len(l), ch[0], ch[1])
+    return blob, best
+
+
+@pytest.mark.parametrize("case,prof,optimize", [("tiny", 0, True), ("tiny", 1, True), ("tiny", 2, True), ("mid", 0, False),
+                                                ("mid", 1, True), ("mid", 2, True), ("cd3", 0, True), ("cd3", 1, False)])
+def test_whole_sac_file_identical_to_reference_program(ctx, sacfiles, case, prof, optimize):
+    # "ref+opt" (SURVEY 7.3): Optimize runs (optimize=True) but the stream is coded with the base profile, so the file
+    # must be the reference's byte for byte either way
+    if not oracle_lib.have_ref():
+        pytest.skip("oracle/_ref not built")
+    seed, rate, n = [int(x) for x in sacfiles[f"{case}_params"]]
+    blob, best = gpu_sac_file(ctx, oracle_lib.Ref(), seed, rate, n, prof, optimize)
+    assert len(blob) == int(sacfiles[f"{case}{prof}_len"])
+    assert hashlib.sha256(blob).digest() == sacfiles[f"{case}{prof}_sha"].tobytes()
+    if f"{case}{prof}_sac" in sacfiles:
+        assert blob == sacfiles[f"{case}{prof}_sac"].tobytes()
+    if optimize:  # the optimizer did run: its selections are finite values inside the profile's ranges
+        pr = sacopt.base_profile(prof)
+        assert np.all(best >= pr[:, 0] - 1e-12) and np.all(best <= pr[:, 1] + 1e-12)
+
+
+# ---------------------------------------------------------------- BASELINE configs[4]: 24-bit 96 kHz, 8 channels = 4 pairs
+def config5_pairs():
+    return [stereo_clip(320 + k, 384000, rate=96000, bits=24) for k in range(4)]
+
+
+def test_config5_optimizer_vs_reference(ctx, c5):
+    # the four stereo pairs of an 8-channel 384000-sample frame as one batch: Optimize (84 GetCost on 48000-sample
+    # windows) + the full-frame pass in one call. Pair 0 against rows written by the REAL reference (r_*): winners,
+    # all 84 (coef, x, cost) rows, the full-frame residuals (SHA-256) and maxbpn.
+    frames = config5_pairs()
+    best, traces, rows = ctx.optimize(2, frames)
+    assert list(rows) == [84] * 4
+    assert same_bits(best[0], c5["r_best"]) and same_bits(traces[0], c5["r_trace"])
+    best_e, outs = ctx.encode(2, frames)
+    assert same_bits(best_e, best)
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a, dtype=np.int32).tobytes()).digest()
+    assert sha(outs[0]["e0"]) == c5["r_e0_sha"].tobytes() and sha(outs[0]["e1"]) == c5["r_e1_sha"].tobytes()
+    assert list(outs[0]["maxbpn"][:2]) == list(c5["r_maxbpn"])
+
+
+def test_ols32_stage_vs_reference_class(ctx, golden, c5):
+    # LPC3(0.997, S = 24, D = 8, k = 8, regp = 500): rows from the reference's own class (lpc.h:181 takes S and D)
+    p0, p1 = ctx.lpc3_pair(0.997, golden["pred_L"][:3000], golden["pred_R"][:3000], S=24, D=8)
+    assert same_bits(p0, c5["lpc32_p0"]) and same_bits(p1, c5["lpc32_p1"])
+
+
+def test_ols32_cascade_vs_oracle(ctx, golden, c5, oracle):
+    # SACOPT_PROFILE_HIGH32 = StereoHigh with that 32-tap OLS stage. PARITY UNPINNED: no reference profile has this shape
+    # (profile.cpp:116 hard-codes 16 + 8); rows o32* come from the oracle (restatement), not from the reference.
+    out = ctx.predict(3, [(golden["pred_L"], golden["pred_R"])], frm=[0], n=[4096])[0]
+    assert np.array_equal(out["e0"], c5["o32_e0"]) and np.array_equal(out["e1"], c5["o32_e1"])
+    best, traces, rows = ctx.optimize(3, [stereo_clip(12, 8192)])
+    assert rows[0] == 84 and same_bits(best[0], c5["o32s_best"]) and same_bits(traces[0], c5["o32s_trace"])
+    # pipelined full-frame pass + degenerate inputs, live against the oracle
+    L, R = stereo_clip(52, 50000)
+    o = ctx.predict(3, [(L, R)], maps=True)[0]
+    ref = oracle.predict(3, L, R, maps=True)
+    for k in ("e0", "e1", "u0", "u1", "m0", "m1", "maxbpn"):
+        assert np.array_equal(o[k], ref[k]), k
+    with pytest.raises(sacopt.SacoptError, match="24-tap"):
+        ctx.unpredict(3, [dict(e0=o["e0"], e1=o["e1"])])
+
+
+def test_config5_ols32_optimizer_vs_oracle(ctx, c5):
+    # configs[4] proper: 32-tap OLS, 24-bit 96 kHz pair, full optimizer on the 48000-sample window (oracle rows, unpinned)
+    frames = config5_pairs()[1:2]
+    best, traces, rows = ctx.optimize(3, frames)
+    assert rows[0] == 84 and same_bits(best[0], c5["o32_best"]) and same_bits(traces[0], c5["o32_trace"])
+
+
+# ---------------------------------------------------------------- the optimiser's parameters in the stream
+@pytest.mark.parametrize("prof", [0, 1, 2])
+def test_parameter_stream_round_trip(prof):
+    # opt-in extension (sac_amd/host/sacfile.h): header flag + per-frame {coefs, minval/maxval}. Encode: Optimize, then
+    # PredictStereoFrame with the WINNERS (two GPU passes), reference bit-plane coder, container writer. Decode: container
+    # reader, reference bit-plane decoder, UnpredictStereoFrame on the GPU with the frame's own parameters -> the WAV samples.
+    if not oracle_lib.have_ref():
+        pytest.skip("oracle/_ref not built")
+    ref = oracle_lib.Ref()
+    rate, n = 2000, 19000
+    L, R = stereo_clip(601, n, rate=rate)
+    fs = 4 * rate
+    frames = [(L[a:a + fs], R[a:a + fs]) for a in range(0, n, fs)]
+    with sacopt.Context(0) as c:   # this host's rsqrtss on both sides, as a real encoder run
+        best, _, _ = c.optimize(prof, frames, ncoef_loop=sacopt.NCOEF[prof])
+        outs = c.predict(prof, frames, coefs=best, maps=True)
+        nolimit = (-2 ** 31, 2 ** 31 - 1, -2 ** 31, 2 ** 31 - 1)   # StereoHigh::Unpredict's clamp (profile.cpp:163,170) made a no-op:
+        blob = sacfile.write_header(2, rate, 16, n, prof | sacfile.PROFILE_PARAMS, sacfile.canonical_wav_metadata(2, rate, 16, n))
+        for (l, r), o, b in zip(frames, outs, best):               # the encoder does not clamp, so the decoder must not either
+            ch = oracle_lib.ref_encode_channels(ref, prof, l, r, o)
+            blob += sacfile.write_frame(len(l), ch[0], ch[1], params=(b, nolimit))
+        # ---- decode from the bytes alone
+        hdr, pos = sacfile.read_header(blob)
+        assert hdr["profile"] == (prof | sacfile.PROFILE_PARAMS) and hdr["numsamples"] == n
+        dec_in, coefs = [], []
+        left = n
+        while left > 0:
+            rec, used = sacfile.read_frame(blob, pos, with_params=True)
+            pos += used
+            left -= rec["numsamples"]
+            e0, e1, u0, u1 = oracle_lib.ref_decode_channels(ref, prof, rec["numsamples"], rec["ch"][0], rec["ch"][1])
+            dec_in.append(dict(e0=e0, e1=e1, used0=u0, used1=u1, minmax=rec["minmax"]))
+            coefs.append(rec["coefs"])
+        assert pos == len(blob)
+        assert same_bits(np.stack(coefs), best)
+        dec = c.unpredict(prof, dec_in, coefs=np.stack(coefs))
+        got_l = np.concatenate([v[0] for v in dec]); got_r = np.concatenate([v[1] for v in dec])
+        assert np.array_equal(got_l, L) and np.array_equal(got_r, R)

@@ -1,5 +1,6 @@
 """Marginal real-time cost of the phases of k_lms<1280,640> (debug flags of sacopt_lms_pair) on
 realistic stage inputs (LPC3 residual of the synthetic clip's optimizer window)."""
+import os as _os; _os.environ.setdefault("SACOPT_LIB", _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "_ablate", "libsacopt.so"))  # instrumented build: make -C tools
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -16,3 +17,5 @@ for mode in modes:
     os.environ["SACOPT_DBG"] = str(mode)
     ctx.lms_pair(1280, 640, 1e-5, 5e-6, x0, x1); t = ctx.last_timing()
     print(f"mode {mode:4d} (256=two-channel kernel,8=serial chain,16=single P2,2=no update): {2.4e6*t['total_ms']/n:8.0f} cyc/sample", flush=True)
+
+ctx.close()

@@ -1,5 +1,6 @@
 """(256,128) stage on realistic stage inputs: time per sample and how often the exact first half misses wave 1's 32
 candidates (debug flag 128 of sacopt_lms_pair)."""
+import os as _os; _os.environ.setdefault("SACOPT_LIB", _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "_ablate", "libsacopt.so"))  # instrumented build: make -C tools
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -20,3 +21,5 @@ for seed, off in ((1000, 77175), (1003, 20000)):
     r0, r1 = ctx.lms_pair(256, 128, 5e-4, 1e-4, y0, y1)
     os.environ.pop("SACOPT_DBG", None)
     print(f"seed {seed}: {1e3 * t['total_ms'] / n:.3f} us/sample ({2.4e3 * t['total_ms'] / n:.0f} cycles), misses per sample {r0[0] / n:.4f}")
+
+ctx.close()

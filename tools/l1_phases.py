@@ -2,6 +2,7 @@
 per sample: [0] products until the first barrier is reached, [1] from there until the wave reaches the barrier after the
 sum (waiting at the first barrier + P1 + internal barrier + walk/verification for wave 0), [2] waiting at that barrier,
 [3] update."""
+import os as _os; _os.environ.setdefault("SACOPT_LIB", _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "_prof", "libsacopt.so"))  # instrumented build: make -C tools
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -18,3 +19,5 @@ ph = (q0[:64].reshape(16, 4) / n).round().astype(int)
 print("wave: products | to-barrier-after-sum | wait | update   (cycles per sample), total", ph[0].sum())
 for w in range(16):
     print(w, list(ph[w]))
+
+ctx.close()

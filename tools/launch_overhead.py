@@ -15,3 +15,5 @@ for n in (512, 1024, 2048, 4096, 8192, 16384, 32768):
     for _ in range(3):
         ctx.lms_pair(1280, 640, 1e-5, 5e-6, x0[:n], x1[:n]); ts.append(ctx.last_timing()["lms_ms"])
     print(f"n {n:6d}: kernel {min(ts):8.3f} ms  {1e3 * min(ts) / n:6.3f} us/sample", flush=True)
+
+ctx.close()

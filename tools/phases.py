@@ -1,4 +1,5 @@
 """P2 passes per sample of k_lms1c (debug flag 128 of sacopt_lms_pair) on realistic stage inputs."""
+import os as _os; _os.environ.setdefault("SACOPT_LIB", _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "_ablate", "libsacopt.so"))  # instrumented build: make -C tools
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -17,3 +18,5 @@ for seed, off in ((1000, 77175), (1003, 20000)):
         a0, a1 = int(q0[0]), int(q1[0])
         print(f"seed {seed} dbg {extra}: P2 passes per sample: ch0 {(a0 & 0xffffffff) / n:.3f}  ch1 {(a1 & 0xffffffff) / n:.3f}"
               f"   walk iterations per sample (dbg 1024): ch0 {(a0 >> 32) / n:.3f}  ch1 {(a1 >> 32) / n:.3f}")
+
+ctx.close()

@@ -17,3 +17,5 @@ for prof, name in ((0, "fast"), (1, "normal"), (2, "high")):
     t = time.perf_counter(); ctx.encode(prof, frames, device_out=outs); torch.cuda.synchronize()
     dt = time.perf_counter() - t
     print(f"{name:7s} encode (optimize + predict + remap) {dt * 1000:8.1f} ms  {NF * FRAME / dt / 1e6:7.2f} M samples/s", flush=True)
+
+ctx.close()

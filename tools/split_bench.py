@@ -17,3 +17,5 @@ for name, fn in (("optimize", lambda: ctx.optimize(2, frames)), ("predict", lamb
     fn(); torch.cuda.synchronize()
     t = time.perf_counter(); fn(); fn(); torch.cuda.synchronize()
     print(f"{name:9s} {(time.perf_counter() - t) * 500:8.1f} ms")
+
+ctx.close()

@@ -17,3 +17,5 @@ for rep in range(2):
     ctx.lpc3_pair(0.997, L, R); t = ctx.last_timing(); print(f"lpc3    : {t['total_ms']:8.2f} ms  {1e3*t['total_ms']/n:7.3f} us/sample")
     for prof in (0, 1, 2):
         ctx.predict(prof, [(L, R)]); t = ctx.last_timing(); print(f"predict{prof}: {t['total_ms']:8.2f} ms  {1e3*t['total_ms']/n:7.3f} us/sample")
+
+ctx.close()

@@ -19,3 +19,5 @@ for prof in (0, 1, 2):
     lt = ctx.last_timing(); tot, kms = lt["total_ms"], lt["lms_ms"]
     print(f"profile {prof}: {nfr} frames x {n}: kernel {kms:.1f} ms, call {tot:.1f} ms, wall {wall*1e3:.1f} ms, "
           f"{nfr*n/(tot*1e-3)/1e6:.2f} M samples/s, {kms*1e3/n:.3f} us/sample/frame, round trip {'ok' if ok else 'MISMATCH'}", flush=True)
+
+ctx.close()

@@ -19,3 +19,5 @@ for name, prof, e, kw, want in unpredict_cases(g):
             print(name, "ch", c, "first mismatch at", i, "of", len(want[c]), "n_bad", len(bad), "got", v[c][i:i+4], "want", want[c][i:i+4], "e", e[c][i:i+4])
         else:
             print(name, "ch", c, "ok")
+
+ctx.close()
