@@ -139,6 +139,18 @@ int sacopt_unpredict_stereo_frames(sacopt_ctx *ctx, int profile, int nframes, co
 int sacopt_cost_golomb(sacopt_ctx *ctx, const int32_t *buf, int n, double *state_inout, double *cost);
 int sacopt_cost_meanrms(sacopt_ctx *ctx, const int32_t *buf, int n, double *cost);
 
+/* ---- CostGolomb::Calc without any allocation ------------------------------------------------------------------
+ * NO COUNTERPART IN THE REFERENCE. Same arguments, result and state handling as sacopt_cost_golomb, for callers that
+ * cannot allocate: code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc. The staging copy of
+ * a host `buf` and the kernels' partial results (the buffer is costed in parallel segments whose guessed start states are
+ * verified, see kernels.hip) live in a file-scope device array of 4 MiB + 1.6 KiB that every GPU the library runs on
+ * holds until the process ends; the call makes no hipMalloc / hipFree / hipHostMalloc, creates no event and touches
+ * neither the context's arena nor its staging memory. Limits: n <= SACOPT_NOALLOC_MAX_SAMPLES (larger n is an error, as
+ * is a NULL ctx); all calls on one GPU -- from any context -- share that GPU's array, so calls that overlap on one GPU
+ * race: serialise them. */
+#define SACOPT_NOALLOC_MAX_SAMPLES (1 << 20)
+int sacopt_cost_golomb_noalloc(sacopt_ctx *ctx, const int32_t *buf, int n, double *state_inout, double *cost);
+
 /* ---- stage-level entry points (used by the parity tests to pin single kernels) --------------- */
 /* Stereo pair of LMSADA2(S,D,mu1,mu2) (src/pred/nlms.h:96-139) driven as the cascades drive them.
  * Supported (S,D): (1280,640) (256,128) (32,16) (8,4). x/p are host or device doubles. */

@@ -1318,6 +1318,63 @@ __global__ void k_cost_fin(const CostJob *__restrict__ jobs, int njobs) {
   *job.ok = ok ? 1 : 0;
 }
 
+// ------------------------------------------------------------------------------------------
+// CostGolomb::Calc of ONE buffer, segment-parallel, for sacopt_cost_golomb_noalloc (include/sacopt.h): the buffer is cut into
+// segments of COST_SEG samples and the scheme of k_cost_tail/par/fin above is applied to the segments: the mean at the end
+// of segment b is GUESSED from its last COST_WARM samples, every segment is costed from the guessed end of its predecessor
+// (segment 0: the caller's state), and the result stands only if every actual end EQUALS the guess its successor started
+// from (induction from the caller's state); otherwise one wave walks the whole buffer. The bit counts are integers (exact in
+// FP64 in any order, < 2^53), so nbits = sum of the segments' sums.
+// ctl: [0] state (in/out), [1] cost (out), [2] verified flag (as double), [8 + b] F, [8 + NS + b] E, [8 + 2 NS + b] bits
+// ------------------------------------------------------------------------------------------
+#define COST_SEG 16384
+#define NOALLOC_MAX_N (1 << 20)                     /* samples per call */
+#define NOALLOC_MAX_SEG (NOALLOC_MAX_N / COST_SEG)  /* 64 */
+#define NOALLOC_CTL_DOUBLES (8 + 3 * NOALLOC_MAX_SEG)
+#define NOALLOC_STAGE_BYTES ((size_t)NOALLOC_MAX_N * 4)
+#define NOALLOC_BYTES (NOALLOC_STAGE_BYTES + NOALLOC_CTL_DOUBLES * 8)
+// The scratch of the entry point that allocates nothing: staged input (host callers) + the control block above. One copy
+// per GPU, for the life of the process. In host code this NAME is only a handle: its device address is taken once per
+// device with hipGetSymbolAddress (sacopt_noalloc_scratch below) and only that pointer is ever handed to a kernel or a copy.
+static __device__ __align__(256) unsigned char scratch[NOALLOC_BYTES];
+
+__global__ __launch_bounds__(64) void k_cseg_tail(const int32_t *__restrict__ e, int n, double *__restrict__ ctl, const int *__restrict__ pow2_bits) {
+  __shared__ CostLds L;
+  const int b = blockIdx.x, end = min(n, (b + 1) * COST_SEG);  // only segments that have a successor: end = (b+1)*COST_SEG < n
+  double mean = 0.;
+  cost_buffer(e, end - COST_WARM, end, mean, false, threadIdx.x, pow2_bits, L);
+  if (threadIdx.x == 0) ctl[8 + b] = mean;
+}
+__global__ __launch_bounds__(64) void k_cseg_par(const int32_t *__restrict__ e, int n, int nseg, double *__restrict__ ctl, const int *__restrict__ pow2_bits) {
+  __shared__ CostLds L;
+  const int b = blockIdx.x, from = b * COST_SEG, end = min(n, from + COST_SEG);
+  double mean = b ? ctl[8 + b - 1] : ctl[0];
+  const long long tot = cost_buffer(e, from, end, mean, true, threadIdx.x, pow2_bits, L);
+  if (threadIdx.x == 0) {
+    ctl[8 + NOALLOC_MAX_SEG + b] = mean;
+    ctl[8 + 2 * NOALLOC_MAX_SEG + b] = (double)tot;
+  }
+}
+// one wave: verification and, when it fails, the sequential walk
+__global__ __launch_bounds__(64) void k_cseg_fin(const int32_t *__restrict__ e, int n, int nseg, double *__restrict__ ctl, const int *__restrict__ pow2_bits) {
+  __shared__ CostLds L;
+  bool ok = true;
+  for (int b = 0; b + 1 < nseg; b++) ok = ok && (__double_as_longlong(ctl[8 + b]) == __double_as_longlong(ctl[8 + NOALLOC_MAX_SEG + b]));
+  double mean, nbits = 0.;
+  if (ok) {
+    for (int b = 0; b < nseg; b++) nbits += ctl[8 + 2 * NOALLOC_MAX_SEG + b];
+    mean = ctl[8 + NOALLOC_MAX_SEG + nseg - 1];
+  } else {
+    mean = ctl[0];
+    nbits = (double)cost_buffer(e, 0, n, mean, true, threadIdx.x, pow2_bits, L);  // valid in lane 0
+  }
+  if (threadIdx.x == 0) {
+    ctl[0] = mean;
+    ctl[1] = nbits / (double)n;  // codec.cpp:335
+    ctl[2] = ok ? 1. : 0.;
+  }
+}
+
 // single buffer variant used by sacopt_cost_golomb / meanrms
 __global__ void k_meanrms(const int32_t *e, int n, double *out) {
   // CostMeanRMS::Calc (codec.cpp:302-312): sum of |e| as integers (exact in FP64), / n
@@ -1516,6 +1573,31 @@ extern "C" int sacopt_launch_cost_par(const CostJob *jobs, int njobs, int nbuf, 
   hipLaunchKernelGGL(k_cost_par, dim3(nbuf, njobs), dim3(64), 0, st, jobs, pow2_bits);
   hipLaunchKernelGGL(k_cost_fin, dim3((njobs + 63) / 64), dim3(64), 0, st, jobs, njobs);
   hipLaunchKernelGGL(k_cost, dim3(njobs), dim3(64), 0, st, jobs, pow2_bits);
+  return hipGetLastError() != hipSuccess;
+}
+// ---- the entry point that allocates nothing (sacopt_cost_golomb_noalloc) -------------------------------------------------
+// Device address of `scratch` on the CURRENT device, looked up once per device (every GPU has its own copy at its own address).
+extern "C" int sacopt_noalloc_scratch(int device, void **ptr, size_t *stage_bytes, size_t *ctl_doubles, int *max_n) {
+  static void *dev_ptr[64];  // per device; written once under the caller's create call (sacopt_create is not re-entrant per device)
+  if (device < 0 || device >= 64) return 1;
+  if (!dev_ptr[device]) {
+    void *p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess || !p) { (void)hipGetLastError(); return 1; }
+    dev_ptr[device] = p;
+  }
+  *ptr = dev_ptr[device];
+  *stage_bytes = NOALLOC_STAGE_BYTES;
+  *ctl_doubles = NOALLOC_CTL_DOUBLES;
+  *max_n = NOALLOC_MAX_N;
+  return 0;
+}
+// e: n residuals on the device (1 <= n <= NOALLOC_MAX_N); ctl: the control block inside the scratch (ctl[0] = state in).
+extern "C" int sacopt_launch_cost_noalloc(const int32_t *e, int n, double *ctl, const int *pow2_bits, hipStream_t st) {
+  if (n <= 0 || n > NOALLOC_MAX_N) return 1;
+  const int nseg = (n + COST_SEG - 1) / COST_SEG;
+  if (nseg > 1) hipLaunchKernelGGL(k_cseg_tail, dim3(nseg - 1), dim3(64), 0, st, e, n, ctl, pow2_bits);
+  hipLaunchKernelGGL(k_cseg_par, dim3(nseg), dim3(64), 0, st, e, n, nseg, ctl, pow2_bits);
+  hipLaunchKernelGGL(k_cseg_fin, dim3(1), dim3(64), 0, st, e, n, nseg, ctl, pow2_bits);
   return hipGetLastError() != hipSuccess;
 }
 extern "C" int sacopt_launch_meanrms(const int32_t *e, int n, double *out, hipStream_t st) {

@@ -33,6 +33,8 @@ int sacopt_launch_meanrms(const int32_t *e, int n, double *out, hipStream_t st);
 int sacopt_launch_rls(int ns, const double *pv, const double *val, int len, double alpha, double *p, hipStream_t st);
 int sacopt_launch_map(const MapJob *jobs, int njobs, int max_numsamples, int max_n, hipStream_t st);
 int sacopt_launch_unpredict(int type, const UnJob *jobs, int njobs, const uint16_t *tab, int bits, hipStream_t st);
+int sacopt_noalloc_scratch(int device, void **ptr, size_t *stage_bytes, size_t *ctl_doubles, int *max_n);
+int sacopt_launch_cost_noalloc(const int32_t *e, int n, double *ctl, const int *pow2_bits, hipStream_t st);
 }
 
 static thread_local std::string g_create_error;
@@ -73,6 +75,10 @@ struct sacopt_ctx {
     std::vector<int> n;                 // window length per frame
     size_t mark = 0;                    // arena position behind the kept data
   } kept;
+  // sacopt_cost_golomb_noalloc: device address of this GPU's file-scope scratch array (kernels.hip), taken once at create
+  unsigned char *na_scratch = nullptr;
+  size_t na_stage_bytes = 0, na_ctl_doubles = 0;
+  int na_max_n = 0;
 };
 
 #define HIPCK(ctx, call)                                                                          \
@@ -303,6 +309,11 @@ extern "C" int sacopt_create(int device, const float *rsqrt_tab, int rsqrt_bits,
   if (hipMalloc(&c->d_pow2, sizeof(pw)) != hipSuccess) return fail("hipMalloc failed");
   if (hipMemcpy(c->d_pow2, pw, sizeof(pw), hipMemcpyHostToDevice) != hipSuccess) return fail("upload failed");
   if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) return fail("hipEventCreate failed");
+  {  // this device's copy of the static scratch (hipGetSymbolAddress with the device current; the array's name is no address)
+    void *p = nullptr;
+    if (sacopt_noalloc_scratch(device, &p, &c->na_stage_bytes, &c->na_ctl_doubles, &c->na_max_n)) return fail("hipGetSymbolAddress(scratch) failed");
+    c->na_scratch = static_cast<unsigned char *>(p);
+  }
   *out = c;
   return 0;
 }
@@ -1582,6 +1593,36 @@ extern "C" int sacopt_cost_golomb(sacopt_ctx *c, const int32_t *buf, int n, doub
   HIPCK(c, hipMemcpyAsync(cost, d_cost, 8, hipMemcpyDeviceToHost, c->st));
   if (state_inout) HIPCK(c, hipMemcpyAsync(state_inout, d_state, 8, hipMemcpyDeviceToHost, c->st));
   return end_timing(c);
+}
+
+// CostGolomb::Calc that allocates nothing (include/sacopt.h): staging + partial results live in the per-GPU static scratch.
+// No hipMalloc/hipFree/hipHostMalloc, no event creation, no arena, no std::vector: pointer checks, at most three copies,
+// one memset and three kernel launches on c->st, then a stream synchronise.
+extern "C" int sacopt_cost_golomb_noalloc(sacopt_ctx *c, const int32_t *buf, int n, double *state_inout, double *cost) {
+  if (!c) return 1;
+  HIPCK(c, hipSetDevice(c->device));
+  c->err.clear();
+  if (n < 0 || !cost || (n && !buf)) { c->err = "bad arguments"; return 1; }
+  if (n > c->na_max_n) { c->err = "sacopt_cost_golomb_noalloc: n exceeds the static scratch (at most 1048576 samples per call)"; return 1; }
+  if (n == 0) { *cost = 0.; return 0; }  // codec.cpp:335: empty buffer -> 0, state untouched
+  HIPCK(c, hipStreamSynchronize(c->st));  // an earlier call that failed half-way may have left work on the stream
+  double *ctl = reinterpret_cast<double *>(c->na_scratch + c->na_stage_bytes);
+  const int32_t *d = buf;
+  if (!is_device_ptr(buf)) {
+    HIPCK(c, hipMemcpyAsync(c->na_scratch, buf, (size_t)n * 4, hipMemcpyHostToDevice, c->st));
+    d = reinterpret_cast<const int32_t *>(c->na_scratch);
+  }
+  // the scratch keeps the last call's contents: the control block starts from zero, then the caller's state goes in
+  HIPCK(c, hipMemsetAsync(ctl, 0, c->na_ctl_doubles * 8, c->st));
+  const double st0 = state_inout ? *state_inout : 0.;
+  HIPCK(c, hipMemcpyAsync(ctl, &st0, 8, hipMemcpyHostToDevice, c->st));
+  if (sacopt_launch_cost_noalloc(d, n, ctl, c->d_pow2, c->st)) { c->err = "k_cseg launch failed"; return 1; }
+  double res[2];
+  HIPCK(c, hipMemcpyAsync(res, ctl, 16, hipMemcpyDeviceToHost, c->st));
+  HIPCK(c, hipStreamSynchronize(c->st));
+  if (state_inout) *state_inout = res[0];
+  *cost = res[1];
+  return 0;
 }
 
 extern "C" int sacopt_cost_meanrms(sacopt_ctx *c, const int32_t *buf, int n, double *cost) {

@@ -58,6 +58,7 @@ def lib():
         L.sacopt_encode_frames.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.sacopt_unpredict_stereo_frames.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.sacopt_cost_golomb.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.sacopt_cost_golomb_noalloc.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.sacopt_cost_meanrms.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.sacopt_lms_pair.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p,
                                       C.c_int, C.c_void_p, C.c_void_p]
@@ -69,7 +70,7 @@ def lib():
 
 
 EXPORTS = ["sacopt_create", "sacopt_destroy", "sacopt_last_error", "sacopt_probe_rsqrt", "sacopt_base_profile",
-           "sacopt_predict_stereo_frames", "sacopt_get_costs", "sacopt_recost_last", "sacopt_optimize_frames", "sacopt_encode_frames", "sacopt_unpredict_stereo_frames", "sacopt_cost_golomb",
+           "sacopt_predict_stereo_frames", "sacopt_get_costs", "sacopt_recost_last", "sacopt_optimize_frames", "sacopt_encode_frames", "sacopt_unpredict_stereo_frames", "sacopt_cost_golomb", "sacopt_cost_golomb_noalloc",
            "sacopt_cost_meanrms", "sacopt_lms_pair", "sacopt_lpc3_pair", "sacopt_rls_run", "sacopt_last_timing"]
 
 
@@ -300,6 +301,19 @@ class Context:
         else:
             buf, n = buf
         self._ck(lib().sacopt_cost_golomb(self._h, _p(buf), n, _p(st), _p(cost)))
+        return float(cost[0]), float(st[0])
+
+    def cost_golomb_noalloc(self, buf, state=0.0):
+        """sacopt_cost_golomb_noalloc: same contract as cost_golomb, no allocation inside the library.
+        buf: numpy int32 array, or (raw device pointer, n)."""
+        st = np.array([state], np.float64)
+        cost = np.zeros(1)
+        if isinstance(buf, np.ndarray):
+            buf = np.ascontiguousarray(buf, dtype=np.int32)
+            n = len(buf)
+        else:
+            buf, n = buf
+        self._ck(lib().sacopt_cost_golomb_noalloc(self._h, _p(buf), n, _p(st), _p(cost)))
         return float(cost[0]), float(st[0])
 
     def cost_meanrms(self, buf):
