@@ -1,17 +1,21 @@
 #!/usr/bin/env python3
 """bench.py -- optimize-mode encode throughput of the sac optimizer/predictor path on MI355X.
 
-One "step" = one pass of the hot path over one 60 s synthetic 16-bit 44.1 kHz stereo clip per
-GPU (15 frames of 176400 samples): FrameCoder::Optimize (84 candidate evaluations per frame on
-the centre 1/8 window, high profile) + the final full-frame PredictStereoFrame with the base
-profile ("ref+opt") -- BASELINE.json configs[2]. Inputs are resident in HBM
-before the timed region. N>1: every rank (one per GPU) encodes its own clip (frames/files shard
-without any collective); value = all ranks' input samples / max-over-ranks time.
+One "step" = one pass of the hot path over one batch of frames per GPU: FrameCoder::Optimize (84 candidate evaluations
+per frame on the centre 1/8 window, high profile) + the final full-frame PredictStereoFrame with the base profile
+("ref+opt"), i.e. FrameCoder::Predict with the optimizer enabled. Bit-plane / range coding and file I/O
+are NOT in the timed region (they stay on the host by the north star): `value` is the hot path's throughput, the
+`end_to_end` object prices the host coder beside it.
 
-Prints ONE JSON line (rank 0).
+  N = 1  BASELINE.json configs[2]: one 60 s synthetic 16-bit 44.1 kHz stereo clip (15 frames x 176400).
+  N > 1  BASELINE.json configs[3]'s shape, weak-scaled: N five-minute tracks (75 frames x 176400 each; configs[3] is 64 of
+         them), the global frame list cut with sac_amd.dist.frame_shard (contiguous ranges, one per rank), one library
+         call of 75 frames per rank and step, the per-frame result rows (8 selected parameters + 4 maxbpn) all-gathered in
+         frame order with sac_amd.dist.gather_frame_rows over RCCL inside the timed region. No collective on the data path.
+
+Inputs are resident in HBM before the timed region. Prints ONE JSON line (rank 0).
 """
 import argparse
-import ctypes as C
 import json
 import os
 import sys
@@ -23,36 +27,41 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FRAME = 176400            # 4 s @ 44.1 kHz (src/codec.cpp:533)
-NFRAMES = 15              # 60 s clip
+NFRAMES = 15              # 60 s clip (configs[2])
+TRACK_FRAMES = 75         # 5-minute track (configs[3])
 FLOPS_LMS1 = 2 * (11 * 1920 + 1)   # algorithmic FP64 flops per stereo sample of LMSADA2(1280,640) x 2 ch
 FLOPS_UNIT_HIGH = 58934            # per candidate stereo sample, whole high cascade
 FP64_VECTOR_PEAK_TFLOPS = 78.6     # MI355X datasheet vector FP64
 
 
-def cpu_baseline(seconds_budget=20.0):
-    """The reference's own Optimize + PredictStereoFrame (oracle/_ref, kind 'reference') or the C
-    restatement (kind 'port') on ONE host core, on a bounded sample: one frame of 131072 samples."""
+def cpu_baseline():
+    """The reference's own code (oracle/_ref, kind 'reference'; else the C restatement, 'port') on ONE host core, on a
+    bounded sample of the same workload: Optimize + PredictStereoFrame of ONE real 176400-sample frame (~20-25 s), and --
+    reference only -- its bit-plane/range coder Encode() (codec.cpp:469-472) on the same frame: `host_coder`, the part of
+    an encode that stays on the host."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
     from sac_amd.synth import stereo_clip
-    n = 131072     # ~15-25 s on one core
-    L, R = stereo_clip(1, n)
-    if oracle_lib.have_ref():
-        ref = oracle_lib.Ref()
-        kind = "reference"
+    n = FRAME
+    L, R = stereo_clip(1000, n)    # frame 0 of the benchmark clip
+    have = oracle_lib.have_ref()
+    lib = oracle_lib.Ref() if have else oracle_lib.Oracle()
+    t0 = time.perf_counter()
+    lib.optimize(2, L, R)
+    res = lib.predict(2, L, R, maps=True)
+    dt = time.perf_counter() - t0
+    out = {"value": n / dt, "unit": "samples/s", "cores": 1, "kind": "reference" if have else "port",
+           "sample": f"Optimize (84 candidates x {n // 8}-sample window) + full PredictStereoFrame of one {n}-sample high-profile "
+                     f"frame (frame 0 of the benchmark clip), {dt:.1f} s on one core"}
+    if have:
+        import ctypes as C
+        a = [np.ascontiguousarray(res[k], dtype=np.int32) for k in ("u0", "u1", "m0", "m1", "maxbpn")]
         t0 = time.perf_counter()
-        ref.optimize(2, L, R)
-        ref.predict(2, L, R)
-        dt = time.perf_counter() - t0
-    else:
-        orc = oracle_lib.Oracle()
-        kind = "port"
-        t0 = time.perf_counter()
-        orc.optimize(2, L, R)
-        orc.predict(2, L, R)
-        dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "samples/s", "cores": 1, "kind": kind,
-            "sample": f"Optimize (84 candidates x {n // 8}-sample window) + full PredictStereoFrame of one {n}-sample high-profile frame, {dt:.1f} s on one core"}
+        size = lib.lib.ref_encode_only(C.c_int(2), oracle_lib._ptr(L), oracle_lib._ptr(R), C.c_int(n), *[oracle_lib._ptr(x) for x in a])
+        dte = time.perf_counter() - t0
+        out["host_coder"] = {"value": n / dte, "unit": "samples/s", "cores": 1, "seconds_per_frame": dte, "coded_bytes": int(size),
+                             "sample": "the reference's FrameCoder::Encode() (both BitplaneCoder variants per channel) on that frame's residuals"}
+    return out
 
 
 def decode_extra(ctx, torch, nfr, dL, dR, e0, e1):
@@ -81,22 +90,41 @@ def decode_extra(ctx, torch, nfr, dL, dR, e0, e1):
     return out
 
 
-def large_batch_extra(ctx, torch, dev, stereo_clip, sacopt, nfr=75):
-    """Not the headline: the same call on a 5-minute track (75 frames, BASELINE configs[3]'s unit) -- with more chains than
-    CUs the chip is full and throughput is higher than on the 60 s clip, whose 15 serial chains bound the call."""
-    L, R = stereo_clip(2000, nfr * FRAME)
+def make_batch(torch, dev, stereo_clip, seed, nfr):
+    L, R = stereo_clip(seed, nfr * FRAME)
     dL = torch.from_numpy(L).to(dev); dR = torch.from_numpy(R).to(dev)
     o = [torch.empty_like(dL) for _ in range(4)]
     frames = [(dL.data_ptr() + 4 * f * FRAME, dR.data_ptr() + 4 * f * FRAME, FRAME) for f in range(nfr)]
     outs = [dict(e0=o[0].data_ptr() + 4 * f * FRAME, e1=o[1].data_ptr() + 4 * f * FRAME, u0=o[2].data_ptr() + 4 * f * FRAME,
                  u1=o[3].data_ptr() + 4 * f * FRAME) for f in range(nfr)]
-    ctx.encode(sacopt.PROFILE_HIGH, frames, device_out=outs)
+    return dict(L=L, R=R, dL=dL, dR=dR, o=o, frames=frames, outs=outs)
+
+
+def large_batch_extra(ctx, torch, dev, stereo_clip, sacopt, nfr=TRACK_FRAMES):
+    """Not the headline: the same call on a 5-minute track (75 frames, BASELINE configs[3]'s unit, what every rank runs at
+    N > 1) -- with more chains than CUs the chip is full and throughput is higher than on the 60 s clip, whose 15 serial
+    chains bound the call."""
+    b = make_batch(torch, dev, stereo_clip, 2000, nfr)
+    ctx.encode(sacopt.PROFILE_HIGH, b["frames"], device_out=b["outs"])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    ctx.encode(sacopt.PROFILE_HIGH, frames, device_out=outs)
+    ctx.encode(sacopt.PROFILE_HIGH, b["frames"], device_out=b["outs"])
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     return {"workload": f"{nfr} frames x {FRAME} (300 s track), same call", "ms": 1e3 * dt, "value": nfr * FRAME / dt, "unit": "samples/s"}
+
+
+def apply_params_extra(ctx, torch, sacopt, b, nfr):
+    """Not the headline: SURVEY §8f.2's opt-in mode, where the stream is coded with the parameters Optimize selected: the
+    full-frame pass depends on the optimizer's result, so the two cannot overlap (two library calls)."""
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    best, _, _ = ctx.optimize(sacopt.PROFILE_HIGH, b["frames"])
+    ctx.predict(sacopt.PROFILE_HIGH, b["frames"], coefs=best, device_out=b["outs"])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"workload": f"Optimize, then PredictStereoFrame with the selected parameters ({nfr} frames, no overlap possible)",
+            "ms": 1e3 * dt, "value": nfr * FRAME / dt, "unit": "samples/s"}
 
 
 def pmc_traffic():
@@ -122,10 +150,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--frames", type=int, default=NFRAMES)
+    ap.add_argument("--frames", type=int, default=0, help="frames per GPU and step (default: 15 at N=1, 75 at N>1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true", help="skip the (untimed) decoder-side extra")
     ap.add_argument("--no-large-batch", action="store_true", help="skip the (untimed) 75-frame extra")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 path)")
+    ap.add_argument("--rehearse-one-gpu", action="store_true", help="all ranks on GPU 0 (rehearsal of the N > 1 path on a one-GPU box; needs --backend gloo)")
     args = ap.parse_args()
 
     import torch
@@ -133,38 +163,45 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.rehearse_one_gpu:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
     from sac_amd import sacopt
+    from sac_amd.dist import frame_shard, gather_frame_rows
     from sac_amd.synth import stereo_clip
 
-    nfr = args.frames
-    L, R = stereo_clip(1000 + rank, nfr * FRAME)
-    dL = torch.from_numpy(L).to(dev)
-    dR = torch.from_numpy(R).to(dev)
-    e0 = torch.empty_like(dL); e1 = torch.empty_like(dL)
-    u0 = torch.empty_like(dL); u1 = torch.empty_like(dL)
-    frames = [(dL.data_ptr() + 4 * f * FRAME, dR.data_ptr() + 4 * f * FRAME, FRAME) for f in range(nfr)]
-    outs = [dict(e0=e0.data_ptr() + 4 * f * FRAME, e1=e1.data_ptr() + 4 * f * FRAME,
-                 u0=u0.data_ptr() + 4 * f * FRAME, u1=u1.data_ptr() + 4 * f * FRAME) for f in range(nfr)]
+    per_gpu = args.frames or (NFRAMES if world == 1 else TRACK_FRAMES)
+    total_frames = per_gpu * world
+    lo, hi = frame_shard(total_frames, world, rank)      # contiguous frame range of this rank (= its own track at N > 1)
+    nfr = hi - lo
+    b = make_batch(torch, dev, stereo_clip, 1000 + rank, nfr)
+    frames, outs = b["frames"], b["outs"]
     ctx = sacopt.Context(local_rank)   # rsqrtss table probed from this host's CPU, as the reference would see it
 
     lms_ms = 0.0; lms_launches = 0; lms_units = 0
+    table = None
 
     def step(timed):
-        nonlocal lms_ms, lms_launches, lms_units
+        nonlocal lms_ms, lms_launches, lms_units, table
         # FrameCoder::Predict with Optimize enabled: optimizer + final full-frame pass in one call
-        best, _ = ctx.encode(sacopt.PROFILE_HIGH, frames, device_out=outs)
+        best, res = ctx.encode(sacopt.PROFILE_HIGH, frames, device_out=outs)
         t1 = ctx.last_timing()
         if timed:
             lms_ms += t1["lms_ms"]
             lms_launches += t1["lms_launches"]
             lms_units += t1["lms_units"]
-        return best, np.full(nfr, 84)
+        if world > 1:   # what the writer rank needs from every frame, in frame order (RCCL all-gather of 96 B per frame)
+            rows = np.concatenate([best, np.stack([r["maxbpn"] for r in res]).astype(np.float64)], axis=1)
+            table = gather_frame_rows(rows, total_frames, world, rank)
+        return best
 
     def sync():
         torch.cuda.synchronize()
@@ -177,38 +214,55 @@ def main():
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        best, rows = step(True)
+        best = step(True)
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    samples = nfr * FRAME * world * args.steps
+    samples = total_frames * FRAME * args.steps
+    # ---- outside the timed region: the number of GetCost calls is measured (not assumed), and the overlapped call is
+    # checked against Optimize and PredictStereoFrame run separately, so that a broken overlap cannot post a number
+    best_o, _, rows = ctx.optimize(sacopt.PROFILE_HIGH, frames[:2])
+    chk = ctx.predict(sacopt.PROFILE_HIGH, frames[:1])[0]
+    e0_enc = b["o"][0][:FRAME].cpu().numpy()
+    verified = bool(best_o.tobytes() == best[:2].tobytes() and np.array_equal(chk["e0"], e0_enc))
+    if world > 1:
+        assert table is not None and table.shape == (total_frames, 12) and table[lo:hi, :8].tobytes() == best.tobytes()
     if rank == 0:
-        cand_units = int(rows.sum()) * (FRAME // 8) + nfr * FRAME   # candidate stereo samples per step (algorithmic)
+        cand = int(rows[0])
+        cand_units = total_frames * (cand * (FRAME // 8) + FRAME)   # candidate stereo samples per step (algorithmic)
         avg_launch_s = (lms_ms / 1e3) / max(lms_launches, 1)
         units_per_launch = lms_units / max(lms_launches, 1)
         achieved = units_per_launch * FLOPS_LMS1 / avg_launch_s / 1e12 if lms_launches else 0.0
+        wgs = 2 * nfr if nfr <= 20 else nfr   # per-channel kernel: two workgroups per frame; two-channel kernel: one
+        if world == 1:
+            workload = (f"{nfr * 4} s synthetic 16-bit 44.1 kHz stereo clip ({nfr} frames x {FRAME}), high profile, full optimizer population "
+                        f"({cand} GetCost per frame) + final full-frame predict (BASELINE configs[2]); range coding and file I/O excluded")
+        else:
+            workload = (f"{world} synthetic 5-minute 16-bit 44.1 kHz stereo tracks ({TRACK_FRAMES if not args.frames else per_gpu} frames x {FRAME} each; BASELINE "
+                        f"configs[3]'s shape, one track per GPU instead of 64 in all), high profile, full optimizer population ({cand} GetCost per "
+                        "frame) + final full-frame predict; frames sharded with frame_shard, per-frame rows all-gathered over RCCL; range "
+                        "coding and file I/O excluded")
         line = {
             "metric": "encoded samples/sec (node) in optimize mode", "value": samples / dt, "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{nfr * 4} s synthetic 16-bit 44.1 kHz stereo clip per GPU ({nfr} frames x {FRAME}), high profile, "
-                                   "full optimizer population (84 GetCost per frame) + final full-frame predict (BASELINE configs[2])",
-                       "frames_per_gpu": nfr, "candidates_per_frame": int(rows[0]), "parallelism": f"frames sharded x{world}, no collective"},
-            "algorithmic_tflops_whole_path": cand_units * world * args.steps * FLOPS_UNIT_HIGH / dt / 1e12,
-            "roofline": {"bound": "mfma", "kernel": "k_lms1c",
+            "config": {"workload": workload, "frames_per_gpu": nfr, "candidates_per_frame": cand,
+                       "parallelism": f"frames sharded x{world}, no collective on the data path" + ("" if world == 1 else f"; result rows gathered over {args.backend}"), "checked_against_separate_calls": verified},
+            "algorithmic_tflops_whole_path": cand_units * args.steps * FLOPS_UNIT_HIGH / dt / 1e12,
+            "roofline": {"bound": "mfma", "kernel": "k_lms1c" if nfr <= 20 else "k_lms<1280,640,512,8,2048,true> / k_lms1c (tail chunks)",
                          "note": "FP64 compute bound (78.6 TFLOP/s vector = matrix FP64 peak); the real ceiling is the dependent-add "
                                  "latency of the serial 1920-term sums, the matrix pipe is used as an exact f64 adder, not a GEMM",
                          "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_VECTOR_PEAK_TFLOPS, "traffic": pmc_traffic(),
-                         "workgroups_per_launch": 2 * nfr, "frac_of_occupied_cus": achieved / (FP64_VECTOR_PEAK_TFLOPS * 2 * nfr / 256.0),
+                         "frac": achieved / FP64_VECTOR_PEAK_TFLOPS, "traffic": pmc_traffic() if nfr <= 20 else None,
+                         "workgroups_per_launch": wgs, "frac_of_occupied_cus": achieved / (FP64_VECTOR_PEAK_TFLOPS * min(wgs, 256) / 256.0),
                          "avg_launch_ms": 1e3 * avg_launch_s, "launches": lms_launches,
                          "units_per_launch": units_per_launch, "flops_per_unit": FLOPS_LMS1},
         }
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline()
+            line["cpu_baseline"] = cb = cpu_baseline()
             try:  # frame-parallel on the box's CPU share (16 cores), as its own process: SURVEY §8d (ii)
                 import subprocess
                 out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cpu_baseline_mc.py"), "16", "32768"],
@@ -216,11 +270,28 @@ def main():
                 line["cpu_baseline_all_cores"] = json.loads(out.stdout.strip().splitlines()[-1])
             except Exception as e:  # a reported baseline, never the measurement
                 line["cpu_baseline_all_cores"] = {"error": str(e)[:200]}
+            if "host_coder" in cb:
+                # What an encode of this clip costs end to end when the host keeps the reference's coder: the GPU step plus
+                # Encode() of the frames on `cores` host cores (frames are independent: one frame per core at a time). Derived
+                # from the measured one-core rate of cpu_baseline.host_coder; serial = GPU step then coder, pipelined =
+                # coder of batch k beside the GPU step of batch k+1.
+                cores = 16
+                gpu_s = dt / args.steps
+                coder_s = cb["host_coder"]["seconds_per_frame"] * ((nfr + cores - 1) // cores)
+                line["end_to_end"] = {"cores": cores, "gpu_step_s": gpu_s, "host_coder_s": coder_s,
+                                      "serial_samples_per_s": nfr * FRAME / (gpu_s + coder_s),
+                                      "pipelined_samples_per_s": nfr * FRAME / max(gpu_s, coder_s),
+                                      "note": "host coder = the reference's FrameCoder::Encode() (bit-plane + range coder, unchanged, on the host); "
+                                              "its time is the one-core measurement of cpu_baseline.host_coder x ceil(frames / cores)"}
+        if world == 1 and nfr == NFRAMES:
+            line["apply_selected_parameters"] = apply_params_extra(ctx, torch, sacopt, b, nfr)
         if not args.no_large_batch and world == 1 and nfr == NFRAMES:
             line["large_batch"] = large_batch_extra(ctx, torch, dev, stereo_clip, sacopt)   # untimed extra, not `value`
         if not args.no_decode and world == 1:
-            line["decode"] = decode_extra(ctx, torch, nfr, dL, dR, e0, e1)   # after the timed region, not part of `value`
+            ctx.encode(sacopt.PROFILE_HIGH, frames, device_out=outs)   # residuals of the clip back in the output buffers
+            line["decode"] = decode_extra(ctx, torch, nfr, b["dL"], b["dR"], b["o"][0], b["o"][1])   # after the timed region, not part of `value`
         print(json.dumps(line), flush=True)
+    ctx.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -391,4 +391,21 @@ void ref_decode_channels(int profile, int n, const uint8_t *p0, int len0, int ma
       for (int i = 0; i <= sc; i++) { used[ch][i] = fc.framestats[ch].mymap.usedl[i]; used[ch][sc + 1 + i] = fc.framestats[ch].mymap.usedh[i]; }
     }
 }
+
+// Timing aid for bench.py's cpu_baseline leg: FrameCoder::Encode() alone (codec.cpp:469-472: per channel both
+// BitplaneCoder variants, smaller kept) on residuals computed elsewhere. Returns the two payload sizes summed.
+int ref_encode_only(int profile, const int32_t *s0, const int32_t *s1, int total, const int32_t *u0, const int32_t *u1,
+                    const int32_t *m0, const int32_t *m1, const int *maxbpn) {
+  CoutMute mute;
+  FrameCoder fc(2, total, profile);
+  load_frame(fc, s0, s1, total);
+  for (int i = 0; i < total; i++) {
+    fc.s2u_error[0][i] = u0[i]; fc.s2u_error[1][i] = u1[i];
+    fc.s2u_error_map[0][i] = m0[i]; fc.s2u_error_map[1][i] = m1[i];
+  }
+  fc.framestats[0].maxbpn = maxbpn[0]; fc.framestats[1].maxbpn = maxbpn[1];
+  fc.framestats[0].maxbpn_map = maxbpn[2]; fc.framestats[1].maxbpn_map = maxbpn[3];
+  fc.Encode();
+  return (int)(fc.encoded[0].GetBufPos() + fc.encoded[1].GetBufPos());
+}
 }

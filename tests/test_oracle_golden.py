@@ -115,3 +115,14 @@ def test_unpredict_stereo_frame(oracle, golden_unpredict):
         v = oracle.unpredict(prof, *e, **kw)
         assert np.array_equal(v[0], want[0]) and np.array_equal(v[1], want[1]), name
     assert np.array_equal(g["v2_0"], g["L"]) and np.array_equal(g["vm1_1"], g["Rs"])  # the fixtures are round trips
+
+
+def test_ols32_stage_matches_reference_class(oracle, golden):
+    # LPC3(0.997, 24, 8, 8, 500): the oracle against rows written by the reference's own class (golden_config5.npz: lpc32_*)
+    import os
+    c5 = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_config5.npz"), allow_pickle=False))
+    p0, p1 = oracle.lpc3_pair(0.997, golden["pred_L"][:3000], golden["pred_R"][:3000], S=24, D=8)
+    assert p0.tobytes() == c5["lpc32_p0"].tobytes() and p1.tobytes() == c5["lpc32_p1"].tobytes()
+    # the oracle-made rows of profile 3 are reproducible (they pin the GPU, not the oracle)
+    d = oracle.predict(3, golden["pred_L"], golden["pred_R"], frm=0, n=4096)
+    assert np.array_equal(d["e0"], c5["o32_e0"]) and np.array_equal(d["e1"], c5["o32_e1"])
