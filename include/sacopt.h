@@ -159,13 +159,29 @@ int sacopt_lms_pair(sacopt_ctx *ctx, int S, int D, double mu1, double mu2, const
 /* Stereo pair of LPC3(alpha,S,D,8,500) (src/pred/lpc.h:172-228). Built (S,D): (16,8) as shipped, (24,8). */
 int sacopt_lpc3_pair(sacopt_ctx *ctx, double alpha, int S, int D, const int32_t *s0, const int32_t *s1, int n,
                      double *p0, double *p1);
-/* RLS(nst,alpha) mixer (src/pred/rls.cpp:61-108): p[t] = Predict(pv[t][0..nst)); Update(val[t]). */
+/* RLS(nst,alpha) mixer (src/pred/rls.cpp:61-108): p[t] = Predict(pv[t][0..nst)); Update(val[t]). Runs on the cascades' own
+ * mixer kernel (k_mix), chunked with carried state; pv / val / p are host arrays, pv row-major [len][nst]. */
 int sacopt_rls_run(sacopt_ctx *ctx, int nst, double alpha, const double *pv, const double *val,
                    int len, double *p);
+/* Cholesky::Factor + Solve (src/math/cholesky.cpp:16-77) of one covariance snapshot through the LPC stages' kernel:
+ * snap = packed lower triangle of the n x n matrix (row by row, n(n+1)/2 doubles) followed by b[n]. fast = 0: LPC3's form
+ * (regp 500 added to the diagonal, solutions for every leading order: sol[o(o+1)/2 + i], n = 24 or 32); fast = 1: LPC2's
+ * form (regp 0, one full-order solve: sol[0..n), n = 24). *fail = 1: "matrix indefinit" (lpc.h:216-218), sol untouched. */
+int sacopt_chol_solve(sacopt_ctx *ctx, int n, int fast, const double *snap, double *sol, int *fail);
+/* out[v] = ((0. + x[v][0]) + x[v][1]) + ... : the strict left-to-right FP64 sum of src/pred/nlms.h:110-111 on the device
+ * helpers the LMS kernels use (matrix pipe as an exact adder; nterms 1920: speculative exact summation; 384 / 48 / 12: one
+ * MFMA chain). x: count vectors of nterms doubles, host or device. */
+int sacopt_serial_sum(sacopt_ctx *ctx, int nterms, const double *x, int count, double *out);
+/* Stage outputs of one cascade run over a whole frame (normal / high profiles; coefs NULL = base profile), as the stage
+ * kernels hand them on: p_out[s][ch][t] = stage s prediction (s = 0: LPC3, then the LMS stages; the reference's p[s],
+ * src/profile.cpp:128-132), v_out[s][ch][t] = val[ch][s+1](t), the next stage's input (profile.cpp:141-148). Host arrays
+ * of (1 + number of LMS stages) x 2 x numsamples doubles each. */
+int sacopt_cascade_trace(sacopt_ctx *ctx, int profile, const sacopt_frame *frame, const double *coefs, double *p_out, double *v_out);
 
 /* Timing of the last call, measured with HIP events on the library's own streams: total device
  * ms, and for the dominant kernel (high profile: k_lms1c, the per-channel LMSADA2(1280,640)
- * kernel; other profiles: their first LMS stage): summed launch durations in ms, launch count
+ * kernel, in calls of up to 20 frames, the two-channel kernel of the same stage in larger ones; other profiles: their
+ * first LMS stage): summed launch durations in ms, launch count
  * and stereo samples processed by those launches. No counterpart in the reference (measurement
  * only). */
 int sacopt_last_timing(const sacopt_ctx *ctx, double *total_ms, double *lms_ms, int *lms_launches,

@@ -65,6 +65,24 @@ float ref_rsqrt(float x) { return rsqrt(x); }
 
 int ref_cholesky_test() { Cholesky c(4); return c.Test() ? 1 : 0; }
 
+// The reference's Cholesky class on one matrix: snap = packed lower triangle + b[n] (layout of oracle_chol_solve).
+int ref_chol_solve(int n, double regp, int fast, const double *snap, double *sol) {
+  Cholesky c(n);
+  c.regp = regp;
+  Matrix A(n);
+  for (int r = 0, k = 0; r < n; r++)
+    for (int q = 0; q <= r; q++, k++) { A[r][q] = snap[k]; A[q][r] = snap[k]; }
+  std::vector<double> b(snap + n * (n + 1) / 2, snap + n * (n + 1) / 2 + n);
+  if (c.Factor(A)) return 1;
+  if (fast) { std::vector<double> x(n); c.Solve(b, x); for (int i = 0; i < n; i++) sol[i] = x[i]; }
+  else {
+    c.Solve(b);
+    for (int o = 0; o < n; o++)
+      for (int i = 0; i <= o; i++) sol[o * (o + 1) / 2 + i] = c.sol[o][i];
+  }
+  return 0;
+}
+
 // Base profile table (codec.cpp:8-30): writes ncoef x {vmin,vmax,vdef}, returns ncoef.
 int ref_base_profile(int profile, double *out) {
   FrameCoder fc(2, 16, profile);

@@ -252,6 +252,28 @@ int oracle_cholesky_kat(void) { /* cholesky.cpp:3-14, EPS = 1e-14 (global.h:11) 
   return d < 1E-14;
 }
 
+/* Factor + Solve of one matrix (stage-level driver): snap = packed lower triangle (row by row) + b[n]; fast = 0: all-orders
+ * Solve(b) into sol[o(o+1)/2 + i] with `regp` on the diagonal; fast = 1: Solve(b, x) into sol[0..n). Returns 1 = indefinit. */
+int oracle_chol_solve(int n, double regp, int fast, const double *snap, double *sol) {
+  static double A[NMAX][NMAX];
+  chol_t c;
+  if (n > NMAX) return -1;
+  chol_init(&c, n);
+  c.regp = regp;
+  memset(A, 0, sizeof(A));
+  for (int r = 0, k = 0; r < n; r++)
+    for (int q = 0; q <= r; q++, k++) { A[r][q] = snap[k]; A[q][r] = snap[k]; }
+  const double *b = snap + n * (n + 1) / 2;
+  if (chol_factor(&c, A)) return 1;
+  if (fast) chol_solve_x(&c, b, sol);
+  else {
+    chol_solve_all(&c, b);
+    for (int o = 0; o < n; o++)
+      for (int i = 0; i <= o; i++) sol[o * (o + 1) / 2 + i] = c.sol[o][i];
+  }
+  return 0;
+}
+
 /* ------------------------------------------------------------------ BlendErr (src/pred/blend.h:7-53) */
 typedef struct {
   int n;

@@ -26,6 +26,7 @@ int   oracle_probe_rsqrt(float *tab, int cap);
 
 int    oracle_base_profile(int profile, double *out /* ncoef x {vmin,vmax,vdef} */);
 int    oracle_cholesky_kat(void);
+int    oracle_chol_solve(int n, double regp, int fast, const double *snap, double *sol);
 
 /* FrameCoder::PredictStereoFrame (src/codec.cpp:154-214). s0/s1 hold the whole frame
  * (`total` samples, used for Remap::Analyse as FrameCoder::Predict does, codec.cpp:448-452);
@@ -68,3 +69,4 @@ void oracle_remap_map(const int32_t *src, int n, const int32_t *pred, const int3
 }
 #endif
 #endif
+

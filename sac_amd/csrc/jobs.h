@@ -54,6 +54,8 @@ struct MixJob {
   double alpha;
   int32_t n, t0;           // absolute times [t0, t0+n)
   double *state;           // RLS P,w (+max) carried between chunks ([2][MIX_STATE] doubles); NULL = single launch
+  double *pout[2];         // RLS predictions p[t] (stage-level test entry sacopt_rls_run only; NULL in the cascades)
+  int32_t direct;          // 1: pk[k] already are the mixer inputs pv[k] (sacopt_rls_run); 0: pv = cumulative sums of pk (profile.cpp:134)
 };
 #define MIX_STATE 24
 

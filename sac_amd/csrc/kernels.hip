@@ -1100,6 +1100,8 @@ __global__ __launch_bounds__(64) void k_mix(const MixJob *__restrict__ jobs, int
 #pragma unroll
   for (int k = 0; k < NS; k++) pk[k] = job.pk[k][ch];
   int32_t *eo = job.e[ch], *uo = job.u[ch];
+  double *po = job.pout[ch];
+  const bool direct = job.direct != 0;
   const bool inm = i < NS && j < NS, writer = (lane & 15) == 0;
   double w[NS], P = (inm && i == j) ? 1. : 0.;
 #pragma unroll
@@ -1132,7 +1134,7 @@ __global__ __launch_bounds__(64) void k_mix(const MixJob *__restrict__ jobs, int
       double h[NS];
       h[0] = npk[0];
 #pragma unroll
-      for (int k = 1; k < NS; k++) h[k] = h[k - 1] + npk[k];  // pv (profile.cpp:134)
+      for (int k = 1; k < NS; k++) h[k] = direct ? npk[k] : h[k - 1] + npk[k];  // pv (profile.cpp:134)
       const double cp0 = np0, cx1 = nx1;
       const int32_t v = ns;
       if (it + 1 < n) {
@@ -1152,6 +1154,7 @@ __global__ __launch_bounds__(64) void k_mix(const MixJob *__restrict__ jobs, int
       if (writer) {
         if (eo) eo[t] = e;
         if (uo) uo[t] = ue;
+        if (po) po[t] = p;
       }
       umax = ue > umax ? ue : umax;
       // RLS::Update(val[ch][1]) (rls.cpp:80-108)
@@ -1390,33 +1393,6 @@ __global__ void k_meanrms(const int32_t *e, int n, double *out) {
   }
 }
 
-// RLS stand-alone driver (sacopt_rls_run): p[t] = Predict(pv[t]); Update(val[t]).
-template <int NS>
-__global__ void k_rls(const double *pv, const double *val, int len, double alpha, double *pout) {
-  if (threadIdx.x || blockIdx.x) return;
-  double w[NS], P[NS][NS];
-  for (int i = 0; i < NS; i++) { w[i] = 0.; for (int j = 0; j < NS; j++) P[i][j] = (i == j) ? 1. : 0.; }
-  for (int t = 0; t < len; t++) {
-    double hist[NS];
-    for (int k = 0; k < NS; k++) hist[k] = pv[t * NS + k];
-    double p = 0.;
-    for (int i = 0; i < NS; i++) p += hist[i] * w[i];
-    pout[t] = p;
-    double vt1[NS], kk[NS], m2[NS][NS];
-    for (int i = 0; i < NS; i++) { double sum = 0.; for (int j = 0; j < NS; j++) sum += P[i][j] * hist[j]; vt1[i] = sum; }
-    double inner = 0.;
-    for (int i = 0; i < NS; i++) inner += hist[i] * vt1[i];
-    const double sc = 1. / (alpha + inner);
-    for (int i = 0; i < NS; i++) kk[i] = sc * vt1[i];
-    for (int i = 0; i < NS; i++)
-      for (int j = 0; j < NS; j++) { double sum = 0.; for (int k = 0; k < NS; k++) sum += (kk[i] * hist[k]) * P[k][j]; m2[i][j] = sum; }
-    const double ia = 1. / alpha;
-    for (int i = 0; i < NS; i++) for (int j = 0; j < NS; j++) P[i][j] = ia * (P[i][j] - m2[i][j]);
-    const double dv = val[t] - p;
-    for (int i = 0; i < NS; i++) w[i] = w[i] + dv * kk[i];
-  }
-}
-
 // ------------------------------------------------------------------------------------------
 // Remap (src/coder/map.cpp:89-152): Analyse marks the sample values a frame uses; Map(pred,err)
 // counts the used values in (pred, pred+err] (err > 0) or [pred+err, pred) (err < 0). The count
@@ -1473,6 +1449,56 @@ __global__ void k_map_apply(const MapJob *jobs) {  // Remap::Map + S2U + running
   }
   for (int o = 32; o; o >>= 1) { const int t = __shfl_xor(mx, o); mx = t > mx ? t : mx; }
   if ((threadIdx.x & 63) == 0 && mx > 0) atomicMax(job.mmax, mx);
+}
+
+// ------------------------------------------------------------------------------------------
+// Known-answer driver of the exact serial adders (sacopt_serial_sum, tests only -- but it runs the very device helpers the
+// LMS kernels call): out[v] = ((0. + x[0]) + x[1]) + ... + x[N-1] for vector v, by
+//   N = 1920  spec_exact_sum (15 segments of 128 on mfma_pass32, speculation + bit-exact verification), as k_lms1c
+//   N = 384   mfma_chain_lds<6>, as the (256,128) stage's undivided chain
+//   N = 48,12 the v_mfma_f64_4x4x4 builtin chain, as the (32,16) and (8,4) stages
+// One workgroup of 4 waves per vector.
+// ------------------------------------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(256) void k_sumkat(const double *__restrict__ x, double *__restrict__ out) {
+  constexpr int SEG = L1_SEG, SEGP = L1_SEGP, NSEG = 15;
+  __shared__ double prods[N == 1920 ? 16 * SEGP : 2 * (N + 4) + 64];
+  __shared__ double sA[16], sX1;
+  __shared__ int sJ[16][16];
+  const double *xv = x + (size_t)blockIdx.x * N;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < (int)(sizeof(prods) / 8); i += 256) prods[i] = 0.;
+  __syncthreads();
+  if constexpr (N == 1920) {
+    for (int i = tid; i < N; i += 256) prods[(i / SEG) * SEGP + (i % SEG)] = xv[i];
+    __syncthreads();
+    if (tid < NSEG) {  // the guess: any order (here pairwise) -- exactness must not depend on it
+      double a = 0., b = 0.;
+      for (int k = 0; k < SEG; k += 2) { a += prods[tid * SEGP + k]; b += prods[tid * SEGP + k + 1]; }
+      sA[tid] = a + b;
+    }
+    __syncthreads();
+    long long rounds = 0;
+    const double res = spec_exact_sum<NSEG, SEG / 4, SEGP>((uint32_t)(uintptr_t)&prods[0], sJ, &sX1, sA, wave, wave == 0, 0, rounds, lane);
+    if (wave == 0 && lane == 16 * ((NSEG - 1) & 3) + 4 * ((NSEG - 1) >> 2)) out[blockIdx.x] = res;
+  } else {
+    constexpr int T4 = N / 4, TP = N + 4;
+    for (int i = tid; i < N; i += 256) { prods[i] = xv[i]; prods[TP + i] = xv[i]; }  // the stages' two-channel operand layout
+    __syncthreads();
+    if (wave == 0) {
+      const double *mp = &prods[((lane & 15) & 1) * TP + (lane >> 4)];
+      double acc = 0.;
+      if constexpr (T4 % 16 == 0) acc = mfma_chain_lds<T4 / 16>((uint32_t)(uintptr_t)mp);
+      else {
+        double a[T4];
+#pragma unroll
+        for (int u = 0; u < T4; u++) a[u] = mp[4 * u];
+#pragma unroll
+        for (int u = 0; u < T4; u++) acc = __builtin_amdgcn_mfma_f64_4x4x4f64(a[u], 1.0, acc, 0, 0, 0);
+      }
+      if (lane == 0) out[blockIdx.x] = acc;
+    }
+  }
 }
 
 #include "unpredict.h"
@@ -1604,10 +1630,20 @@ extern "C" int sacopt_launch_meanrms(const int32_t *e, int n, double *out, hipSt
   hipLaunchKernelGGL(k_meanrms, dim3(1), dim3(256), 0, st, e, n, out);
   return hipGetLastError() != hipSuccess;
 }
-extern "C" int sacopt_launch_rls(int ns, const double *pv, const double *val, int len, double alpha, double *p,
-                                 hipStream_t st) {
-  if (ns == 4) hipLaunchKernelGGL((k_rls<4>), dim3(1), dim3(64), 0, st, pv, val, len, alpha, p);
-  else if (ns == 3) hipLaunchKernelGGL((k_rls<3>), dim3(1), dim3(64), 0, st, pv, val, len, alpha, p);
+// Stage-level test entries: one Cholesky snapshot through k_chol; serial sums through the MFMA adder helpers.
+extern "C" int sacopt_launch_chol(const LpcJob *job, int n, int fast, hipStream_t st) {
+  if (fast && n == 24) hipLaunchKernelGGL((k_chol<true, 24>), dim3(1, 1), dim3(64), 0, st, job);
+  else if (!fast && n == 24) hipLaunchKernelGGL((k_chol<false, 24>), dim3(1, 1), dim3(64), 0, st, job);
+  else if (!fast && n == 32) hipLaunchKernelGGL((k_chol<false, 32>), dim3(1, 1), dim3(64), 0, st, job);
+  else return 1;
+  return hipGetLastError() != hipSuccess;
+}
+extern "C" int sacopt_launch_sumkat(int nterms, const double *x, int count, double *out, hipStream_t st) {
+  if (count <= 0) return 0;
+  if (nterms == 1920) hipLaunchKernelGGL((k_sumkat<1920>), dim3(count), dim3(256), 0, st, x, out);
+  else if (nterms == 384) hipLaunchKernelGGL((k_sumkat<384>), dim3(count), dim3(256), 0, st, x, out);
+  else if (nterms == 48) hipLaunchKernelGGL((k_sumkat<48>), dim3(count), dim3(256), 0, st, x, out);
+  else if (nterms == 12) hipLaunchKernelGGL((k_sumkat<12>), dim3(count), dim3(256), 0, st, x, out);
   else return 1;
   return hipGetLastError() != hipSuccess;
 }

@@ -30,7 +30,8 @@ int sacopt_launch_mix(int ns, const MixJob *jobs, int njobs, hipStream_t st);
 int sacopt_launch_cost(const CostJob *jobs, int njobs, const int *pow2_bits, hipStream_t st);
 int sacopt_launch_cost_par(const CostJob *jobs, int njobs, int nbuf, const int *pow2_bits, hipStream_t st);
 int sacopt_launch_meanrms(const int32_t *e, int n, double *out, hipStream_t st);
-int sacopt_launch_rls(int ns, const double *pv, const double *val, int len, double alpha, double *p, hipStream_t st);
+int sacopt_launch_chol(const LpcJob *job, int n, int fast, hipStream_t st);
+int sacopt_launch_sumkat(int nterms, const double *x, int count, double *out, hipStream_t st);
 int sacopt_launch_map(const MapJob *jobs, int njobs, int max_numsamples, int max_n, hipStream_t st);
 int sacopt_launch_unpredict(int type, const UnJob *jobs, int njobs, const uint16_t *tab, int bits, hipStream_t st);
 int sacopt_noalloc_scratch(int device, void **ptr, size_t *stage_bytes, size_t *ctl_doubles, int *max_n);
@@ -67,6 +68,7 @@ struct sacopt_ctx {
   double total_ms = 0, lms_ms = 0;
   int lms_launches = 0;
   long long lms_units = 0;  // stereo samples processed by the timed launches
+  int timed_variant = 1;    // which (1280,640) kernel's launches are timed: 1 = k_lms1c (calls of <= 20 frames), 0 = the two-channel kernel
   // residual buffers of the last sacopt_get_costs call (still in the arena), for sacopt_recost_last
   struct Kept {
     bool valid = false;
@@ -434,6 +436,7 @@ static int begin_call(sacopt_ctx *c) {
   c->lms_launches = 0;
   c->lms_units = 0;
   c->kept.valid = false;  // the arena is about to be reused
+  c->timed_variant = 1;
   return 0;
 }
 static int end_timing(sacopt_ctx *c) {
@@ -718,7 +721,7 @@ static int eval_chains(sacopt_ctx *c, const ProfDesc &pd, const std::vector<DevF
         if (s <= pd.nlms) {
           const StageDesc &sd = pd.lms[s - 1];
           // the dominant kernel (k_lms1c for the high profile, the first LMS stage otherwise) is timed for the roofline
-          const bool dominant = (s == 1) && (sd.S != 1280 || sacopt_lms_variant(sd.S, sd.D, n_jobs[s], c->bits));
+          const bool dominant = (s == 1) && (sd.S != 1280 || sacopt_lms_variant(sd.S, sd.D, n_jobs[s], c->bits) == c->timed_variant);
           hipEvent_t a = nullptr, b = nullptr;
           if (dominant) {
             HIPCK(c, hipEventCreate(&a));
@@ -962,7 +965,7 @@ static int final_pass_enqueue(sacopt_ctx *c, const ProfDesc &pd, const std::vect
   for (int k = 0; k < nchunk; k++) {
     HIPCK(c, hipStreamWaitEvent(sLead, ev_lpc[k], 0));
     hipEvent_t a = nullptr, b = nullptr, e1;
-    const bool dominant = pd.lms[0].S != 1280 || sacopt_lms_variant(pd.lms[0].S, pd.lms[0].D, n_lms[0][k], c->bits);
+    const bool dominant = pd.lms[0].S != 1280 || sacopt_lms_variant(pd.lms[0].S, pd.lms[0].D, n_lms[0][k], c->bits) == c->timed_variant;
     if (dominant) {
       HIPCK(c, hipEventCreate(&a));
       HIPCK(c, hipEventCreate(&b));
@@ -1136,6 +1139,7 @@ extern "C" int sacopt_predict_stereo_frames(sacopt_ctx *c, int profile, int nfra
   if (!get_prof(profile, &pd)) { c->err = "unknown profile"; return 1; }
   if (nframes < 0 || (nframes && (!frames || !out))) { c->err = "bad arguments"; return 1; }
   if (check_frames(c, nframes, frames, from, n)) return 1;
+  c->timed_variant = sacopt_lms_variant(1280, 640, nframes, c->bits);
   double base[3 * SACOPT_MAX_COEFS];
   sacopt_base_profile(profile, base);
   size_t need = 1 << 20;
@@ -1418,6 +1422,7 @@ extern "C" int sacopt_encode_frames(sacopt_ctx *c, int profile, int nframes, con
   double prof[3 * SACOPT_MAX_COEFS];
   sacopt_base_profile(profile, prof);
   if (prof_in) memcpy(prof, prof_in, sizeof(double) * 3 * pd.ncoef);
+  c->timed_variant = sacopt_lms_variant(1280, 640, nframes, c->bits);
   std::vector<std::vector<double>> grid;
   size_t total_cand = 0;
   if (ncoef_loop > 0 && build_grid(c, prof, ncoef_loop, grid, &total_cand)) return 1;
@@ -1701,18 +1706,128 @@ extern "C" int sacopt_lpc3_pair(sacopt_ctx *c, double alpha, int S, int D, const
   return end_timing(c);
 }
 
+// RLS(nst, alpha) driven through the PRODUCT's mixer kernel k_mix<nst> (lane-per-P[i][j] layout, DPP row sums), in chunks of
+// 700 samples with the carried state handed from launch to launch exactly as the cascades' pipelines do.
 extern "C" int sacopt_rls_run(sacopt_ctx *c, int nst, double alpha, const double *pv, const double *val, int len, double *p) {
   if (!c) return 1;
   if (begin_call(c)) return 1;
   if (len < 0 || (len && (!pv || !val || !p))) { c->err = "bad arguments"; return 1; }
   if (nst != 3 && nst != 4) { c->err = "RLS order must be 3 or 4"; return 1; }
   if (!len) return 0;
-  if (arena_reserve(c, (size_t)len * 8 * (nst + 3) + (1 << 16))) return 1;
+  if (arena_reserve(c, (size_t)len * 8 * (nst + 6) + (size_t)len * 4 + (1 << 16) + (size_t)(len / 700 + 2) * (sizeof(MixJob) + 256))) return 1;
   HIPCK(c, hipEventRecord(c->ev0, c->st));
-  const double *dpv, *dval;
-  if (to_dev(c, pv, (size_t)len * nst, &dpv) || to_dev(c, val, len, &dval)) return 1;
-  double *dp = arena_alloc<double>(c, len);
-  if (sacopt_launch_rls(nst, dpv, dval, len, alpha, dp, c->st)) { c->err = "k_rls launch failed"; return 1; }
+  // column k of pv -> its own array (k_mix reads one array per stage)
+  std::vector<double> col((size_t)len);
+  MixJob j;
+  memset(&j, 0, sizeof(j));
+  for (int k = 0; k < nst; k++) {
+    std::vector<double> hv((size_t)len);
+    if (is_device_ptr(pv)) { c->err = "sacopt_rls_run takes host arrays"; return 1; }
+    for (int t = 0; t < len; t++) hv[t] = pv[(size_t)t * nst + k];
+    double *d;
+    if (upload(c, hv, &d)) return 1;
+    j.pk[k][0] = j.pk[k][1] = d;
+  }
+  const double *dval;
+  if (to_dev(c, val, len, &dval)) return 1;
+  int32_t *zs = arena_alloc<int32_t>(c, len);
+  double *zp = arena_alloc<double>(c, len), *dp = arena_alloc<double>(c, len), *dp1 = arena_alloc<double>(c, len);
+  double *state = arena_alloc<double>(c, 2 * MIX_STATE);
+  if (!zs || !zp || !dp || !dp1 || !state) { c->err = "device arena exhausted"; return 1; }
+  HIPCK(c, hipMemsetAsync(zs, 0, (size_t)len * 4, c->st));
+  HIPCK(c, hipMemsetAsync(zp, 0, (size_t)len * 8, c->st));
+  for (int h = 0; h < 2; h++) { j.s[h] = zs; j.p0[h] = zp; j.x1[h] = dval; }
+  j.pout[0] = dp; j.pout[1] = dp1;
+  j.direct = 1;
+  j.alpha = alpha;
+  j.state = state;
+  constexpr int CHUNK = 700;
+  for (int t0 = 0; t0 < len; t0 += CHUNK) {
+    j.t0 = t0;
+    j.n = len - t0 < CHUNK ? len - t0 : CHUNK;
+    std::vector<MixJob> jobs = {j};
+    MixJob *dj;
+    if (upload(c, jobs, &dj)) return 1;
+    if (sacopt_launch_mix(nst, dj, 1, c->st)) { c->err = "k_mix launch failed"; return 1; }
+  }
   if (copy_out(c, p, dp, (size_t)len * 8)) return 1;
+  return end_timing(c);
+}
+
+// One covariance snapshot through k_chol (Cholesky::Factor + Solve, src/math/cholesky.cpp:16-77), as the LPC stages run it.
+extern "C" int sacopt_chol_solve(sacopt_ctx *c, int n, int fast, const double *snap, double *sol, int *fail) {
+  if (!c) return 1;
+  if (begin_call(c)) return 1;
+  if (!snap || !sol || !fail) { c->err = "bad arguments"; return 1; }
+  if (!((n == 24) || (n == 32 && !fast))) { c->err = "built orders: 24 (LPC3 all-orders and LPC2 full-order solve), 32 (LPC3)"; return 1; }
+  const int tri = n * (n + 1) / 2, nsol = fast ? n : tri;
+  if (arena_reserve(c, 1 << 16)) return 1;
+  HIPCK(c, hipEventRecord(c->ev0, c->st));
+  LpcJob j;
+  memset(&j, 0, sizeof(j));
+  std::vector<double> hs(snap, snap + tri + n);
+  double *dsnap;
+  if (upload(c, hs, &dsnap)) return 1;
+  double *dsol = arena_alloc<double>(c, nsol);
+  int32_t *dfail = arena_alloc<int32_t>(c, 2);
+  HIPCK(c, hipMemsetAsync(dsol, 0, (size_t)nsol * 8, c->st));
+  j.snap[0] = dsnap; j.sol[0] = dsol; j.fail[0] = dfail; j.nsnap = 1; j.t0 = 0;
+  std::vector<LpcJob> jobs = {j};
+  LpcJob *dj;
+  if (upload(c, jobs, &dj)) return 1;
+  if (sacopt_launch_chol(dj, n, fast, c->st)) { c->err = "k_chol launch failed"; return 1; }
+  int32_t hf = 0;
+  HIPCK(c, hipMemcpyAsync(sol, dsol, (size_t)nsol * 8, hipMemcpyDeviceToHost, c->st));
+  HIPCK(c, hipMemcpyAsync(&hf, dfail, 4, hipMemcpyDeviceToHost, c->st));
+  if (end_timing(c)) return 1;
+  *fail = hf;
+  return 0;
+}
+
+// Strict left-to-right FP64 sums on the device helpers the LMS kernels use (the matrix pipe as an exact adder).
+extern "C" int sacopt_serial_sum(sacopt_ctx *c, int nterms, const double *x, int count, double *out) {
+  if (!c) return 1;
+  if (begin_call(c)) return 1;
+  if (count < 0 || (count && (!x || !out))) { c->err = "bad arguments"; return 1; }
+  if (nterms != 1920 && nterms != 384 && nterms != 48 && nterms != 12) { c->err = "built chain lengths: 1920, 384, 48, 12"; return 1; }
+  if (!count) return 0;
+  if (arena_reserve(c, (size_t)count * (nterms + 1) * 8 + (1 << 16))) return 1;
+  HIPCK(c, hipEventRecord(c->ev0, c->st));
+  const double *dx;
+  if (to_dev(c, x, (size_t)count * nterms, &dx)) return 1;
+  double *dout = arena_alloc<double>(c, count);
+  if (!dout) { c->err = "device arena exhausted"; return 1; }
+  if (sacopt_launch_sumkat(nterms, dx, count, dout, c->st)) { c->err = "k_sumkat launch failed"; return 1; }
+  if (copy_out(c, out, dout, (size_t)count * 8)) return 1;
+  return end_timing(c);
+}
+
+// Per-stage trace of one cascade run (profile.cpp:126-148): stage predictions p[k] and stage inputs val[ch][k+1] as the stage
+// kernels left them in HBM. p_out / v_out: [nstage][2][n] doubles, nstage = 1 + number of LMS stages (LPC3 first).
+extern "C" int sacopt_cascade_trace(sacopt_ctx *c, int profile, const sacopt_frame *frame, const double *coefs, double *p_out, double *v_out) {
+  if (!c) return 1;
+  if (begin_call(c)) return 1;
+  ProfDesc pd;
+  if (!get_prof(profile, &pd) || pd.type == SACOPT_PROFILE_FAST) { c->err = "cascade trace: normal / high profiles"; return 1; }
+  if (!frame || !p_out || !v_out) { c->err = "bad arguments"; return 1; }
+  if (check_frames(c, 1, frame, nullptr, nullptr)) return 1;
+  const int n = frame->numsamples;
+  if (!n) return 0;
+  double base[3 * SACOPT_MAX_COEFS];
+  sacopt_base_profile(profile, base);
+  if (arena_reserve(c, (1 << 20) + chain_bytes(pd, n) + 2 * (((size_t)n * 4 + 255) & ~(size_t)255) + 4096 + lpc_scratch_bytes(pd, n) + sizeof(LpcJob) + 256)) return 1;
+  HIPCK(c, hipEventRecord(c->ev0, c->st));
+  std::vector<DevFrame> fr;
+  if (stage_frames(c, 1, frame, nullptr, nullptr, fr)) return 1;
+  std::vector<Chain> chains(1);
+  chains[0].frame = 0;
+  for (int i = 0; i < pd.ncoef; i++) chains[0].coefs[i] = coefs ? coefs[i] : base[3 * i + 2];
+  Memo memo;
+  if (eval_chains(c, pd, fr, chains, memo)) return 1;
+  for (int s = 0; s <= pd.nlms; s++)
+    for (int h = 0; h < 2; h++) {
+      if (copy_out(c, p_out + ((size_t)s * 2 + h) * n, chains[0].sb[s].p[h], (size_t)n * 8)) return 1;
+      if (copy_out(c, v_out + ((size_t)s * 2 + h) * n, chains[0].sb[s].xn[h], (size_t)n * 8)) return 1;
+    }
   return end_timing(c);
 }

@@ -64,6 +64,9 @@ def lib():
                                       C.c_int, C.c_void_p, C.c_void_p]
         L.sacopt_lpc3_pair.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.sacopt_rls_run.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.sacopt_chol_solve.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.sacopt_serial_sum.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.sacopt_cascade_trace.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.sacopt_last_timing.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
@@ -71,7 +74,8 @@ def lib():
 
 EXPORTS = ["sacopt_create", "sacopt_destroy", "sacopt_last_error", "sacopt_probe_rsqrt", "sacopt_base_profile",
            "sacopt_predict_stereo_frames", "sacopt_get_costs", "sacopt_recost_last", "sacopt_optimize_frames", "sacopt_encode_frames", "sacopt_unpredict_stereo_frames", "sacopt_cost_golomb", "sacopt_cost_golomb_noalloc",
-           "sacopt_cost_meanrms", "sacopt_lms_pair", "sacopt_lpc3_pair", "sacopt_rls_run", "sacopt_last_timing"]
+           "sacopt_cost_meanrms", "sacopt_lms_pair", "sacopt_lpc3_pair", "sacopt_rls_run", "sacopt_chol_solve", "sacopt_serial_sum",
+           "sacopt_cascade_trace", "sacopt_last_timing"]
 
 
 def _p(a):
@@ -339,6 +343,37 @@ class Context:
         p = np.zeros(len(val))
         self._ck(lib().sacopt_rls_run(self._h, nst, alpha, _p(pv), _p(val), len(val), _p(p)))
         return p
+
+    def chol_solve(self, A, b, fast=False):
+        """A: symmetric n x n (lower triangle used), b: n. Returns (sol, failed): sol = all-orders triangle (fast=False) or x."""
+        A = np.asarray(A, np.float64); n = len(b)
+        snap = np.concatenate([np.concatenate([A[r, :r + 1] for r in range(n)]), np.asarray(b, np.float64)])
+        sol = np.zeros(n if fast else n * (n + 1) // 2)
+        fail = C.c_int(0)
+        self._ck(lib().sacopt_chol_solve(self._h, n, int(fast), _p(snap), _p(sol), C.byref(fail)))
+        return sol, bool(fail.value)
+
+    def serial_sum(self, x):
+        """x: [count, nterms] -> strict left-to-right sums."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        out = np.zeros(x.shape[0])
+        self._ck(lib().sacopt_serial_sum(self._h, x.shape[1], _p(x), x.shape[0], _p(out)))
+        return out
+
+    def cascade_trace(self, profile, s0, s1, coefs=None):
+        """Returns (p[n, 2, nst], v[n, 2, nst]) in the layout of the reference trace fixtures: p[t][ch][k] = stage prediction,
+        v[t][ch][k] = stage input val[ch][k] (k = 0: the sample itself)."""
+        arr, keep = self._frames([(s0, s1)])
+        n = arr[0].numsamples
+        nst = 5 if profile >= 2 else 4
+        po = np.zeros((nst, 2, n)); vo = np.zeros((nst, 2, n))
+        cf = None if coefs is None else np.ascontiguousarray(coefs, dtype=np.float64)
+        self._ck(lib().sacopt_cascade_trace(self._h, profile, arr, _p(cf), _p(po), _p(vo)))
+        p = np.ascontiguousarray(po.transpose(2, 1, 0))
+        v = np.zeros((n, 2, nst))
+        v[:, 0, 0], v[:, 1, 0] = keep[0], keep[1]
+        v[:, :, 1:] = vo.transpose(2, 1, 0)[:, :, :nst - 1]
+        return p, v
 
     def last_timing(self):
         t = C.c_double(); l = C.c_double(); k = C.c_int(); u = C.c_longlong()

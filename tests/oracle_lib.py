@@ -143,6 +143,16 @@ class _Lib:
             f(C.c_int(profile), _ptr(cf), _ptr(e0), _ptr(e1), C.c_int(n), _ptr(u0), _ptr(u1), _ptr(mm), _ptr(v0), _ptr(v1))
         return v0, v1
 
+    def chol_solve(self, A, b, regp, fast=False):
+        """(sol, failed) with the packing of sacopt_chol_solve."""
+        A = np.asarray(A, np.float64); n = len(b)
+        snap = np.ascontiguousarray(np.concatenate([np.concatenate([A[r, :r + 1] for r in range(n)]), np.asarray(b, np.float64)]))
+        sol = np.zeros(n if fast else n * (n + 1) // 2)
+        f = getattr(self.lib, self.pre + "chol_solve")
+        f.restype = C.c_int
+        rc = f(C.c_int(n), C.c_double(regp), C.c_int(int(fast)), _ptr(snap), _ptr(sol))
+        return sol, bool(rc)
+
     def remap_map(self, src, pred, err):
         src = np.ascontiguousarray(src, dtype=np.int32)
         pred = np.ascontiguousarray(pred, dtype=np.int32); err = np.ascontiguousarray(err, dtype=np.int32)

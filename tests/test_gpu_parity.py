@@ -36,8 +36,106 @@ def test_lpc3_pair_golden(ctx, golden):
 
 
 def test_rls_golden(ctx, golden):
+    # sacopt_rls_run drives the cascades' own mixer kernel k_mix<NS> (lane per P[i][j], DPP row sums), 700 samples per
+    # launch with P / w carried from launch to launch as the pipelines carry them
     assert same_bits(ctx.rls_run(4, 0.998, golden["rls_pv"], golden["rls_val"]), golden["rls4_p"])
     assert same_bits(ctx.rls_run(3, 0.998, np.ascontiguousarray(golden["rls_pv"][:, :3]), golden["rls_val"]), golden["rls3_p"])
+
+
+@pytest.mark.parametrize("prof", [1, 2])
+def test_stage_traces_golden(ctx, golden, prof):
+    # every stage's prediction p[k] and input val[ch][k] of the first 96 samples, as the stage kernels hand them on in
+    # HBM, against the reference's own trace (profile.cpp:126-148)
+    p, v = ctx.cascade_trace(prof, golden["pred_L"][:96], golden["pred_R"][:96])
+    assert same_bits(p, golden[f"trace{prof}_p"]) and same_bits(v, golden[f"trace{prof}_v"])
+
+
+def test_stage_traces_vs_oracle_long(ctx, oracle):
+    L, R = stereo_clip(36, 5000)
+    cf = np.array([0.9899, 2e-5, 3e-6, 3e-4, 2e-4, 1e-3, 0.02, 0.9995])
+    p, v = ctx.cascade_trace(2, L, R, coefs=cf)
+    po, vo, _, _ = oracle.cascade_trace(2, L, R, coefs=cf)
+    assert same_bits(p, po) and same_bits(v, vo)
+
+
+def _spd(seed, n):
+    rs = np.random.RandomState(seed)
+    M = rs.randn(n, 3 * n) * 50.0
+    return M @ M.T, rs.randn(n) * 1e4
+
+
+def test_cholesky_kernel(ctx, oracle):
+    # k_chol directly: Cholesky::Test's known answer (cholesky.cpp:3-14; the 4 x 4 system embedded in a 24 x 24 block
+    # diagonal, which leaves every scalar's operation sequence unchanged), random SPD systems of both built orders in both
+    # forms bit-equal to the oracle (itself pinned against the reference class: test_oracle_vs_ref.py::test_chol_solve),
+    # and "matrix indefinit" (lpc.h:216-218)
+    A = np.eye(24); b = np.zeros(24)
+    A[:4, :4] = [[9, 3, -6, 12], [3, 26, -7, -11], [-6, -7, 9, 7], [12, -11, 7, 65]]
+    b[:4] = [72, 34, 22, 326]
+    x, failed = ctx.chol_solve(A, b, fast=True)
+    assert not failed and np.abs(x[:4] - [2, 4, 3, 5]).sum() < 1e-14 and not x[4:].any()
+    assert same_bits(x, oracle.chol_solve(A, b, 0., True)[0])
+    for n, fast in ((24, False), (32, False), (24, True)):
+        for seed in (1, 2):
+            A, b = _spd(seed + n, n)
+            got, failed = ctx.chol_solve(A, b, fast=fast)
+            want, wf = oracle.chol_solve(A, b, 0. if fast else 500., fast)
+            assert not failed and not wf and same_bits(got, want), (n, fast, seed)
+    A, b = _spd(3, 24)
+    A[5, 5] = -1e9
+    assert ctx.chol_solve(A, b)[1] and oracle.chol_solve(A, b, 500., False)[1]
+
+
+def _seq_sum(x):
+    out = np.zeros(x.shape[0])
+    with np.errstate(all="ignore"):
+        for v in range(x.shape[0]):
+            acc = np.float64(0.)
+            for t in x[v]:
+                acc = acc + t      # IEEE double add, round to nearest even: what the reference's loop does (nlms.h:110-111)
+            out[v] = acc
+    return out
+
+
+@pytest.mark.parametrize("nterms", [1920, 384, 48, 12])
+def test_mfma_serial_adder_adversarial(ctx, nterms):
+    # v_mfma_f64_4x4x4 with B == 1 used as an exact serial adder, and the speculative summation built on it: bit-equal to a
+    # sequential host loop on inputs chosen to break an adder that rounds differently, flushes denormals, reorders, or
+    # mishandles signed zeros / infinities / NaN
+    rs = np.random.RandomState(nterms)
+    rows = []
+    rows.append(rs.uniform(-1.5, 1.5, nterms))                                        # benign
+    rows.append(rs.randn(nterms) * 10.0 ** rs.randint(-300, 300, nterms))             # 600 orders of magnitude
+    r = rs.randn(nterms) * 2.0 ** rs.randint(-20, 20, nterms); r[1::2] = -r[::2] * (1 + 2.0 ** -50)   # cancellation over 40 binades
+    rows.append(r)
+    rows.append(rs.randn(nterms) * 5e-324 * rs.randint(1, 1 << 20, nterms))           # denormal terms and partial sums
+    r = rs.randn(nterms) * 1e-310; r[::7] = 2.2250738585072014e-308                   # around the normal / denormal border
+    rows.append(r)
+    r = np.zeros(nterms); r[::2] = -0.0                                               # signed zeros only: (+0) + (-0) = +0
+    rows.append(r)
+    r = np.full(nterms, -0.0); rows.append(r.copy())                                  # all -0: 0. + (-0) = +0 from the start
+    r = rs.randn(nterms); r[nterms // 2] = 1e308; r[nterms // 2 + 1] = 1e308          # overflow to +inf, stays inf
+    rows.append(r)
+    r = rs.randn(nterms); r[3] = np.inf; r[nterms - 2] = -np.inf                      # inf - inf = NaN
+    rows.append(r)
+    r = rs.randn(nterms); r[nterms // 3] = np.nan
+    rows.append(r)
+    r = np.ones(nterms); r[1:] = 2.0 ** -53                                           # ties: 1 + 2^-53 rounds to even every time
+    rows.append(r)
+    r = np.full(nterms, 2.0 ** -53); r[0] = 1 + 2.0 ** -52                            # ties the other way (odd mantissa rounds up)
+    rows.append(r)
+    r = rs.randn(nterms) * 1e15; r[::3] += 0.5                                        # half-ulp patterns at 2^50
+    rows.append(r)
+    for _ in range(6):                                                                # audio-like: products w*h of mixed scale
+        rows.append(rs.randn(nterms) * np.abs(rs.randn(nterms)) * 10.0 ** rs.uniform(-6, 4))
+    x = np.stack(rows)
+    got = ctx.serial_sum(x)
+    want = _seq_sum(x)
+    for v in range(len(rows)):
+        if np.isnan(want[v]):
+            assert np.isnan(got[v]), v      # the payload of a generated NaN is not pinned (x86 gives the "real indefinite" -nan)
+        else:
+            assert got[v:v + 1].tobytes() == want[v:v + 1].tobytes(), (v, got[v], want[v])
 
 
 def test_cost_golden(ctx, golden):

@@ -166,3 +166,27 @@ def test_unpredict_coefs_and_garbage_residuals(pair):
         a = o.unpredict(prof, e0, e1, coefs=cf)
         b = r.unpredict(prof, e0, e1, coefs=cf)
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), prof
+
+
+def _spd(seed, n):
+    rs = np.random.RandomState(seed)
+    M = rs.randn(n, 3 * n) * 50.0
+    return M @ M.T, rs.randn(n) * 1e4
+
+
+def test_chol_solve(pair):
+    # Cholesky::Factor + Solve (cholesky.cpp:16-77): all-orders form with regp (LPC3), full-order form (LPC2), the
+    # Cholesky::Test matrix, and an indefinite matrix ("matrix indefinit": Factor returns 1)
+    o, r = pair
+    for n, regp, fast in ((24, 500., False), (32, 500., False), (24, 0., True), (4, 0., True)):
+        A, b = _spd(n, n)
+        if n == 4:
+            A = np.array([[9, 3, -6, 12], [3, 26, -7, -11], [-6, -7, 9, 7], [12, -11, 7, 65]], float); b = np.array([72., 34, 22, 326])
+        so, fo = o.chol_solve(A, b, regp, fast)
+        sr, fr = r.chol_solve(A, b, regp, fast)
+        assert not fo and not fr and so.tobytes() == sr.tobytes(), n
+        if n == 4:
+            assert np.abs(so - [2, 4, 3, 5]).sum() < 1e-14
+    A, b = _spd(3, 24)
+    A[5, 5] = -1e9
+    assert o.chol_solve(A, b, 500., False)[1] and r.chol_solve(A, b, 500., False)[1]
