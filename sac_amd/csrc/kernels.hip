@@ -711,21 +711,24 @@ __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs
     for (int r = 0; r < R; r++) {
       const double pr = w[r] * h[r];
       if (valid[r]) prods[pa[r]] = pr;
-      part += pr;
+      part = r ? part + pr : pr;
     }
-    // approximate segment sum (tree order: a guess only): 16-lane rows by DPP, then row 0 -> 1 and row 2 -> 3
-    part = row_prefix16(part);
+    // approximate segment sum (tree order: a guess only): 16-lane rows by DPP, then row 0 -> 1 and row 2 -> 3 (and rows 0..1 ->
+    // 2..3 when a whole wave owns the segment). Tried instead: the whole reduction as two v_mfma_f64_4x4x4 (B == 1) + two row
+    // rotations, 12 vector instructions instead of 36 -- 1 % slower: the wave that reaches the barrier last runs this alone on
+    // its SIMD, bound by the latency of the dependent chain, not by vector issue.
     {
+      part = row_prefix16(part);
       int lo = __double2loint(part), hi = __double2hiint(part);
       lo = __builtin_amdgcn_update_dpp(0, lo, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1 and 3
       hi = __builtin_amdgcn_update_dpp(0, hi, 0x142, 0xA, 0xF, false);
       part += __hiloint2double(hi, lo);
-    }
-    if (HW == 64) {
-      int lo = __double2loint(part), hi = __double2hiint(part);
-      lo = __builtin_amdgcn_update_dpp(0, lo, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2 and 3
-      hi = __builtin_amdgcn_update_dpp(0, hi, 0x143, 0xC, 0xF, false);
-      part += __hiloint2double(hi, lo);
+      if (HW == 64) {
+        lo = __double2loint(part); hi = __double2hiint(part);
+        lo = __builtin_amdgcn_update_dpp(0, lo, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2 and 3
+        hi = __builtin_amdgcn_update_dpp(0, hi, 0x143, 0xC, 0xF, false);
+        part += __hiloint2double(hi, lo);
+      }
     }
     if (hl == HW - 1 && valid[0]) sA[seg] = part;
     L1_TICK(0)

@@ -11,7 +11,10 @@
 //                                          (src/codec.h:49) appear as enc_mapped[ch] / used[ch] / minval[ch] / maxval[ch].
 // Buffers are the reference's public members (samples / error / s2u_error / s2u_error_map, src/codec.h:29-31);
 // maxbpn / maxbpn_map stand for framestats[ch].maxbpn{,_map} (src/codec.h:49, src/codec.cpp:207-211).
-// PredictBatch is the batched form a throughput-minded Codec::EncodeFile would call.
+// PredictBatch is the batched form a throughput-minded Codec::EncodeFile would call. With apply = true the
+// frame is predicted with the parameters Optimize selected (the reference codes with baseprofile, :459) --
+// such frames go into a stream whose header carries SAC_PROFILE_PARAMS (sacfile.h): ToRecord / FromRecord move the
+// parameters between a FrameCoder and a FrameRecord.
 // Header-only; link with libsacopt.so. Not thread-safe (like the reference).
 #ifndef SACOPT_FRAMECODER_H
 #define SACOPT_FRAMECODER_H
@@ -21,6 +24,7 @@
 #include <vector>
 
 #include "../../include/sacopt.h"
+#include "sacfile.h"
 
 namespace sacopt {
 
@@ -56,8 +60,9 @@ class FrameCoder {
   }
 
   // Predict() for a batch of frames (same profile type) in one call; frames are independent (codec.cpp:156-159).
-  static void PredictBatch(FrameCoder *const *fc, int nframes, bool optimize) {
+  static void PredictBatch(FrameCoder *const *fc, int nframes, bool optimize, bool apply = false) {
     if (nframes <= 0) return;
+    if (apply) { PredictBatchApply(fc, nframes); return; }
     FrameCoder &f0 = *fc[0];
     const int ncoef = (int)f0.baseprofile.coefs.size();
     std::vector<sacopt_frame> fr(nframes);
@@ -83,6 +88,50 @@ class FrameCoder {
         for (int i = 0; i < ncoef; i++) f.optprofile.coefs[i].vdef = best[(size_t)b * ncoef + i];
       }
     }
+  }
+
+  // Optimize, then PredictStereoFrame(optprofile, 0, 1, 0, numsamples): two library calls, the second needs the first's result
+  static void PredictBatchApply(FrameCoder *const *fc, int nframes) {
+    FrameCoder &f0 = *fc[0];
+    const int ncoef = (int)f0.baseprofile.coefs.size();
+    std::vector<sacopt_frame> fr(nframes);
+    std::vector<sacopt_residuals> out(nframes);
+    std::vector<double> prof(3 * ncoef), best((size_t)nframes * ncoef);
+    for (int i = 0; i < ncoef; i++) { prof[3 * i] = f0.baseprofile.coefs[i].vmin; prof[3 * i + 1] = f0.baseprofile.coefs[i].vmax; prof[3 * i + 2] = f0.baseprofile.coefs[i].vdef; }
+    for (int b = 0; b < nframes; b++) {
+      FrameCoder &f = *fc[b];
+      if (f.baseprofile.type != f0.baseprofile.type) throw std::invalid_argument("mixed profiles in one batch");
+      fr[b] = {f.samples[0].data(), f.samples[1].data(), f.numsamples};
+      out[b] = sacopt_residuals();
+      out[b].err0 = f.error[0].data(); out[b].err1 = f.error[1].data();
+      out[b].s2u0 = f.s2u_error[0].data(); out[b].s2u1 = f.s2u_error[1].data();
+      out[b].map0 = f.s2u_error_map[0].data(); out[b].map1 = f.s2u_error_map[1].data();
+    }
+    f0.check(sacopt_optimize_frames(f0.ctx_, f0.baseprofile.type, nframes, fr.data(), prof.data(), ncoef, best.data(), nullptr, 0, nullptr));
+    f0.check(sacopt_predict_stereo_frames(f0.ctx_, f0.baseprofile.type, nframes, fr.data(), nullptr, nullptr, best.data(), out.data()));
+    for (int b = 0; b < nframes; b++) {
+      FrameCoder &f = *fc[b];
+      f.maxbpn[0] = out[b].maxbpn[0]; f.maxbpn[1] = out[b].maxbpn[1];
+      f.maxbpn_map[0] = out[b].maxbpn[2]; f.maxbpn_map[1] = out[b].maxbpn[3];
+      f.optprofile = f.baseprofile;
+      for (int i = 0; i < ncoef; i++) f.optprofile.coefs[i].vdef = best[(size_t)b * ncoef + i];
+    }
+  }
+  // Per-frame stream fields of the parameter extension (sacfile.h): the frame's optprofile values; minval / maxval are
+  // written as the full int32 range, which makes StereoHigh::Unpredict's clamp (profile.cpp:163,170) the identity -- the
+  // encoder does not clamp (profile.cpp:152,156), so anything narrower would not round-trip.
+  void ToRecord(FrameRecord &rec) const {
+    rec.numsamples = (uint32_t)numsamples;
+    rec.ncoef = (int)optprofile.coefs.size();
+    for (int i = 0; i < rec.ncoef; i++) rec.coefs[i] = optprofile.coefs[i].vdef;
+    for (int c = 0; c < 2; c++) { rec.minval[c] = INT32_MIN; rec.maxval[c] = INT32_MAX; }
+  }
+  void FromRecord(const FrameRecord &rec) {
+    if (rec.ncoef != (int)baseprofile.coefs.size()) throw std::invalid_argument("parameter count of the record does not fit the profile");
+    numsamples = (int)rec.numsamples;
+    optprofile = baseprofile;
+    for (int i = 0; i < rec.ncoef; i++) optprofile.coefs[i].vdef = rec.coefs[i];
+    for (int c = 0; c < 2; c++) { minval[c] = rec.minval[c]; maxval[c] = rec.maxval[c]; enc_mapped[c] = rec.ch[c].enc_mapped; }
   }
 
   void PredictStereoFrame(const SacProfile &profile, int ch0, int ch1, int from, int n) {

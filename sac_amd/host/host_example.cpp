@@ -1,11 +1,13 @@
 // Host-side example / test driver: encodes synthetic frames through sacopt::FrameCoder (the C++ mirror of the
 // reference's FrameCoder on this path) and prints, per frame, the selected parameters and checksums of the
 // residual arrays. tests/test_gpu_parity.py::test_cpp_host_framecoder compares the output with the ctypes path.
-//   usage: host_example <profile> <nframes> <numsamples> <optimize 0|1>
+//   usage: host_example <profile> <nframes> <numsamples> <optimize 0|1|2>     (2: also the "apply" round trip -- frames coded with
+//          the parameters Optimize selected travel through the parameter-extension stream records of sacfile.h and decode back)
 #include <algorithm>
 #include <cinttypes>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <memory>
 
 #include "framecoder.h"
@@ -64,6 +66,52 @@ int main(int argc, char **argv) {
       dec_ok[b] = f.samples[0] == keep0[b] && f.samples[1] == keep1[b];
       f.samples[0] = keep0[b]; f.samples[1] = keep1[b]; f.error[1] = keepe1[b];
     }
+    int apply_ok = -1;
+    if (optimize == 2) {  // predict with optprofile, carry the parameters in the stream, decode with them
+      std::vector<std::unique_ptr<sacopt::FrameCoder>> ac, dc;
+      std::vector<sacopt::FrameCoder *> ap, dp;
+      for (int b = 0; b < nframes; b++) {
+        ac.emplace_back(new sacopt::FrameCoder(ctx, 2, n, profile));
+        ac[b]->samples[0] = fc[b]->samples[0]; ac[b]->samples[1] = fc[b]->samples[1];
+        ac[b]->SetNumSamples(n);
+        ap.push_back(ac[b].get());
+      }
+      sacopt::FrameCoder::PredictBatch(ap.data(), nframes, true, true);
+      // stream: header with the flag, one record per frame; the payload stands in for the host's entropy coder (raw residuals)
+      std::vector<uint8_t> stream;
+      sacopt::SacHeader h;
+      h.numsamples = (uint32_t)(nframes * n); h.profile = (uint32_t)profile | sacopt::SAC_PROFILE_PARAMS;
+      h.metadata = sacopt::CanonicalWavMetadata(2, 44100, 16, h.numsamples);
+      sacopt::WriteHeader(stream, h);
+      for (int b = 0; b < nframes; b++) {
+        sacopt::FrameRecord rec;
+        ac[b]->ToRecord(rec);
+        for (int c = 0; c < 2; c++) {
+          const uint8_t *p = reinterpret_cast<const uint8_t *>(ac[b]->error[c].data());
+          rec.ch[c].payload.assign(p, p + 4 * (size_t)n);
+          rec.ch[c].maxbpn = ac[b]->maxbpn[c];
+        }
+        sacopt::WriteEncoded(stream, rec, true);
+      }
+      sacopt::SacHeader h2;
+      size_t pos = sacopt::ReadHeader(stream.data(), stream.size(), h2);
+      apply_ok = pos && h2.has_params() && (int)h2.profile_type() == profile;
+      for (int b = 0; b < nframes && apply_ok; b++) {
+        sacopt::FrameRecord rec;
+        const size_t used = sacopt::ReadEncoded(stream.data() + pos, stream.size() - pos, rec, true);
+        if (!used) { apply_ok = 0; break; }
+        pos += used;
+        dc.emplace_back(new sacopt::FrameCoder(ctx, 2, n, profile));
+        dc[b]->FromRecord(rec);
+        for (int c = 0; c < 2; c++) memcpy(dc[b]->error[c].data(), rec.ch[c].payload.data(), 4 * (size_t)n);
+        dp.push_back(dc[b].get());
+      }
+      if (apply_ok) {
+        sacopt::FrameCoder::UnpredictBatch(dp.data(), nframes, true);
+        for (int b = 0; b < nframes; b++)
+          apply_ok = apply_ok && dc[b]->samples[0] == fc[b]->samples[0] && dc[b]->samples[1] == fc[b]->samples[1] && pos == stream.size();
+      }
+    }
     for (int b = 0; b < nframes; b++) {
       sacopt::FrameCoder &f = *fc[b];
       printf("frame %d in %016" PRIx64 " %016" PRIx64 " err %016" PRIx64 " %016" PRIx64 " s2u %016" PRIx64 " %016" PRIx64
@@ -72,7 +120,9 @@ int main(int argc, char **argv) {
              fnv(f.s2u_error[0].data(), n), fnv(f.s2u_error[1].data(), n), fnv(f.s2u_error_map[0].data(), n),
              fnv(f.s2u_error_map[1].data(), n), f.maxbpn[0], f.maxbpn[1], f.maxbpn_map[0], f.maxbpn_map[1]);
       for (auto &c : f.optprofile.coefs) printf(" %.17g", c.vdef);
-      printf(" decode %s\n", dec_ok[b] ? "ok" : "MISMATCH");
+      printf(" decode %s", dec_ok[b] ? "ok" : "MISMATCH");
+      if (apply_ok >= 0) printf(" apply %s", apply_ok ? "ok" : "MISMATCH");
+      printf("\n");
     }
   } catch (const std::exception &e) {
     fprintf(stderr, "%s\n", e.what());

@@ -365,7 +365,7 @@ def test_cpp_host_framecoder():
     if not os.path.exists(exe):
         pytest.skip("host_example not built")
     n, nframes = 3000, 2
-    out = subprocess.run([exe, "2", str(nframes), str(n), "1"], capture_output=True, text=True, timeout=120)
+    out = subprocess.run([exe, "2", str(nframes), str(n), "2"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
     lines = [ln.split() for ln in out.stdout.strip().splitlines()]
     assert len(lines) == nframes
@@ -385,6 +385,7 @@ def test_cpp_host_framecoder():
         assert [int(x) for x in ln[15:19]] == list(o["maxbpn"])
         assert same_bits(np.array([float(x) for x in ln[20:28]]), best[b])
         assert ln[28:30] == ["decode", "ok"]  # FrameCoder::Unpredict of the C++ mirror (one channel mapped) restores the samples
+        assert ln[30:32] == ["apply", "ok"]   # frames coded with the SELECTED parameters, carried by sacfile.h's extension records, decode back
 
 
 # ---------------------------------------------------------------- BASELINE sizes (176400-sample frames)
