@@ -154,9 +154,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true", help="skip the (untimed) decoder-side extra")
     ap.add_argument("--no-large-batch", action="store_true", help="skip the (untimed) 75-frame extra")
+    ap.add_argument("--no-extras", action="store_true", help="timed steps only: no baseline, no untimed extras (the command that is profiled)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 path)")
     ap.add_argument("--rehearse-one-gpu", action="store_true", help="all ranks on GPU 0 (rehearsal of the N > 1 path on a one-GPU box; needs --backend gloo)")
     args = ap.parse_args()
+    if args.no_extras:
+        args.no_cpu_baseline = args.no_decode = args.no_large_batch = True
 
     import torch
     import torch.distributed as dist
@@ -224,10 +227,13 @@ def main():
     samples = total_frames * FRAME * args.steps
     # ---- outside the timed region: the number of GetCost calls is measured (not assumed), and the overlapped call is
     # checked against Optimize and PredictStereoFrame run separately, so that a broken overlap cannot post a number
-    best_o, _, rows = ctx.optimize(sacopt.PROFILE_HIGH, frames[:2])
-    chk = ctx.predict(sacopt.PROFILE_HIGH, frames[:1])[0]
-    e0_enc = b["o"][0][:FRAME].cpu().numpy()
-    verified = bool(best_o.tobytes() == best[:2].tobytes() and np.array_equal(chk["e0"], e0_enc))
+    if args.no_extras:
+        rows, verified = np.full(1, 84), None   # profiling runs: nothing but the timed steps touches the GPU
+    else:
+        best_o, _, rows = ctx.optimize(sacopt.PROFILE_HIGH, frames[:2])
+        chk = ctx.predict(sacopt.PROFILE_HIGH, frames[:1])[0]
+        e0_enc = b["o"][0][:FRAME].cpu().numpy()
+        verified = bool(best_o.tobytes() == best[:2].tobytes() and np.array_equal(chk["e0"], e0_enc))
     if world > 1:
         assert table is not None and table.shape == (total_frames, 12) and table[lo:hi, :8].tobytes() == best.tobytes()
     if rank == 0:
@@ -283,7 +289,7 @@ def main():
                                       "pipelined_samples_per_s": nfr * FRAME / max(gpu_s, coder_s),
                                       "note": "host coder = the reference's FrameCoder::Encode() (bit-plane + range coder, unchanged, on the host); "
                                               "its time is the one-core measurement of cpu_baseline.host_coder x ceil(frames / cores)"}
-        if world == 1 and nfr == NFRAMES:
+        if world == 1 and nfr == NFRAMES and not args.no_extras:
             line["apply_selected_parameters"] = apply_params_extra(ctx, torch, sacopt, b, nfr)
         if not args.no_large_batch and world == 1 and nfr == NFRAMES:
             line["large_batch"] = large_batch_extra(ctx, torch, dev, stereo_clip, sacopt)   # untimed extra, not `value`
