@@ -68,5 +68,9 @@ void oracle_remap_map(const int32_t *src, int n, const int32_t *pred, const int3
 #ifdef __cplusplus
 }
 #endif
+/* sac_coder.c: the host-side bit-plane coder, restated; payload sizes / bytes of one channel */
+int oracle_encode_mono_normal(const int32_t *s2u, int numsamples, int maxbpn, unsigned char *out, int cap);
+int oracle_encode_mono_mapped(const int32_t *s2u_map, int numsamples, int maxbpn_map, const unsigned char *used, unsigned char *out, int cap);
+
 #endif
 

@@ -24,8 +24,8 @@ def _ptr(a):
 
 
 def build_oracle():
-    if not os.path.exists(_ORACLE_SO) or os.path.getmtime(_ORACLE_SO) < os.path.getmtime(
-            os.path.join(ROOT, "oracle", "sac_oracle.c")):
+    if not os.path.exists(_ORACLE_SO) or os.path.getmtime(_ORACLE_SO) < max(
+            os.path.getmtime(os.path.join(ROOT, "oracle", f)) for f in ("sac_oracle.c", "sac_coder.c")):
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "oracle"])
     return _ORACLE_SO
 
@@ -195,6 +195,23 @@ class Oracle(_Lib):
         used = np.zeros(2 * 32769, np.uint8)
         self.lib.oracle_remap_tables(_ptr(src), C.c_int(len(src)), _ptr(used))
         return used
+
+    def encode_channel(self, s2u, maxbpn, s2u_map=None, maxbpn_map=0, used=None, want_bytes=True):
+        """FrameCoder::EncodeMonoFrame (codec.cpp:268-280) restated: both coders, the smaller kept ("normal" wins only when
+        strictly smaller). Returns (payload bytes | size, enc_mapped, flag bits); without map inputs only the plain coder runs."""
+        s2u = np.ascontiguousarray(s2u, dtype=np.int32)
+        n = len(s2u)
+        cap = 16 * n + 70000
+        o1 = np.zeros(cap if want_bytes else 1, np.uint8)
+        n1 = self.lib.oracle_encode_mono_normal(_ptr(s2u), C.c_int(n), C.c_int(int(maxbpn)), _ptr(o1) if want_bytes else None, C.c_int(cap if want_bytes else 0))
+        if s2u_map is None:
+            return (o1[:n1].tobytes() if want_bytes else n1), False, int(maxbpn)
+        sm = np.ascontiguousarray(s2u_map, dtype=np.int32); us = np.ascontiguousarray(used, dtype=np.uint8)
+        o2 = np.zeros(cap if want_bytes else 1, np.uint8)
+        n2 = self.lib.oracle_encode_mono_mapped(_ptr(sm), C.c_int(n), C.c_int(int(maxbpn_map)), _ptr(us), _ptr(o2) if want_bytes else None, C.c_int(cap if want_bytes else 0))
+        if n1 < n2:
+            return (o1[:n1].tobytes() if want_bytes else n1), False, int(maxbpn)
+        return (o2[:n2].tobytes() if want_bytes else n2), True, int(maxbpn_map)
 
     def optimize(self, profile, s0, s1, prof=None, ncoef_loop=8, max_rows=128):
         s0 = np.ascontiguousarray(s0, dtype=np.int32); s1 = np.ascontiguousarray(s1, dtype=np.int32)

@@ -190,3 +190,22 @@ def test_chol_solve(pair):
     A, b = _spd(3, 24)
     A[5, 5] = -1e9
     assert o.chol_solve(A, b, 500., False)[1] and r.chol_solve(A, b, 500., False)[1]
+
+
+def test_bitplane_coder_bytes(pair):
+    # SURVEY 8f.4, first half: the bit-plane context-mixing coder + MapEncoder + range coder restated in oracle/sac_coder.c
+    # produce the reference's payload BYTES (FrameCoder::Encode, codec.cpp:237-280), plain and mapped, all profiles'
+    # residual statistics, a sparse-valued clip (the mapped variant wins) and silence
+    import oracle_lib
+    o, r = pair
+    cases = [(0, stereo_clip(26, 5000)), (1, stereo_clip(27, 7000)), (2, stereo_clip(28, 6000)), (1, _sparse_clip(29, 6000)),
+             (0, (np.zeros(1500, np.int32), np.zeros(1500, np.int32)))]
+    mapped_seen = plain_seen = False
+    for prof, (L, R) in cases:
+        res = o.predict(prof, L, R, maps=True)
+        want = oracle_lib.ref_encode_channels(r, prof, L, R, res)
+        for ch, (s, u, m) in enumerate(((L, res["u0"], res["m0"]), (R, res["u1"], res["m1"]))):
+            got = o.encode_channel(u, res["maxbpn"][ch], m, res["maxbpn"][2 + ch], o.remap_tables(s))
+            assert got == want[ch], (prof, ch, len(got[0]), len(want[ch][0]), got[1:], want[ch][1:])
+            mapped_seen |= got[1]; plain_seen |= not got[1]
+    assert mapped_seen and plain_seen

@@ -80,3 +80,20 @@ def test_whole_file_from_oracle_residuals(sacfiles, oracle, prof):
     blob = assemble_sac(lambda p, l, r: oracle.predict(p, l, r, maps=True), seed, rate, n, prof)
     assert blob == sacfiles[f"tiny{prof}_sac"].tobytes()
     assert hashlib.sha256(blob).digest() == sacfiles[f"tiny{prof}_sha"].tobytes()
+
+
+@pytest.mark.parametrize("prof", [0, 1, 2])
+def test_whole_file_without_the_reference(sacfiles, oracle, prof):
+    # nothing of the reference is loaded here: the oracle's predictor AND its restated bit-plane coder (oracle/sac_coder.c)
+    # + this repo's container writer reproduce the file the reference's program wrote
+    seed, rate, n = [int(x) for x in sacfiles["tiny_params"]]
+    L, R = stereo_clip(seed, n, rate=rate)
+    blob = sacfile.write_header(2, rate, 16, n, prof, sacfile.canonical_wav_metadata(2, rate, 16, n))
+    fs = 4 * rate
+    for a in range(0, n, fs):
+        l, r = L[a:a + fs], R[a:a + fs]
+        res = oracle.predict(prof, l, r, maps=True)
+        ch = [oracle.encode_channel(res[f"u{c}"], res["maxbpn"][c], res[f"m{c}"], res["maxbpn"][2 + c], oracle.remap_tables(s))
+              for c, s in enumerate((l, r))]
+        blob += sacfile.write_frame(len(l), ch[0], ch[1])
+    assert blob == sacfiles[f"tiny{prof}_sac"].tobytes()
