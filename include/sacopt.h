@@ -139,6 +139,15 @@ int sacopt_unpredict_stereo_frames(sacopt_ctx *ctx, int profile, int nframes, co
 int sacopt_cost_golomb(sacopt_ctx *ctx, const int32_t *buf, int n, double *state_inout, double *cost);
 int sacopt_cost_meanrms(sacopt_ctx *ctx, const int32_t *buf, int n, double *cost);
 
+/* ---- size of FrameCoder::EncodeMonoFrame_Normal's payload (src/codec.cpp:237-247): BitplaneCoder::Encode (src/coder/vle.cpp:110-138)
+ * over RangeCoderSH (src/coder/range.cpp:52-90) -- SURVEY.md 8f.4 ------------------------------------------------------------
+ * sizes[b] = the number of bytes the host's bit-plane coder writes for the s2u residuals s2u[b][0..n[b]) coded with maxbpn[b]
+ * planes + 1 (framestats[ch].maxbpn, src/codec.cpp:207-208), exactly. One coder per GPU lane, so the call pays off for many
+ * buffers at once (candidates x channels x frames); the bytes themselves stay the host coder's job. s2u: host array of nbuf
+ * host-or-device pointers; n, maxbpn, sizes: host arrays. The coder's logistic tables (src/model/domain.h:12-23) are
+ * tabulated with the libm of the host that created the context, as the reference's static initialiser does. */
+int sacopt_coded_sizes(sacopt_ctx *ctx, int nbuf, const int32_t *const *s2u, const int32_t *n, const int32_t *maxbpn, int32_t *sizes);
+
 /* ---- CostGolomb::Calc without any allocation ------------------------------------------------------------------
  * NO COUNTERPART IN THE REFERENCE. Same arguments, result and state handling as sacopt_cost_golomb, for callers that
  * cannot allocate: code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc. The staging copy of

@@ -1,0 +1,217 @@
+// the size of a channel's payload as the host's bit-plane coder would write it -- BitplaneCoder::Encode
+// (src/coder/vle.cpp:3-138) on RangeCoderSH (src/coder/range.cpp:52-90) with its context models (src/model/counter.h:20-65,
+// mixer.h:56-101, sse.h:88-125, domain.h:6-57), i.e. FrameCoder::EncodeMonoFrame_Normal (src/codec.cpp:237-247) without the
+// bytes. Included by kernels.hip.
+//
+// The coder is one adaptive chain per buffer: every binary decision updates the counters, mixers and the SSE stage the next
+// one reads, bit plane after bit plane. Nothing inside a buffer is parallel, so the parallelism is ACROSS buffers -- the
+// candidates x channels x frames of an optimizer round: one lane per buffer, a wave = 64 coders in lockstep. All arithmetic
+// is the reference's integer arithmetic; the only floating point of the original, the stretch / squash tables of LogDomain
+// (log / exp of the host libm), is tabulated by the host at sacopt_create and read from LDS.
+//   LDS (per wave):  stretch table 32768 x int16, squash table 4096 x uint16, 1/(n+3) table, and per lane the 322 bit
+//                    counters and 42 mixer weights ([element][lane]: bank = lane, conflict-free whatever the contexts are)
+//   HBM (per wave):  residuals transposed to [sample][lane] (coalesced), msb[sample][lane], and the SSE maps
+//                    [context][2][33][lane] -- (maxbpn+1) x 32 contexts of 264 bytes per lane do not fit the LDS.
+#define BP_PBITS 15
+#define BP_PSCALE (1 << BP_PBITS)
+#define BP_PSCALEm (BP_PSCALE - 1)
+#define BP_WBITS 16
+#define BP_DBITS 12
+#define BP_WRANGE (1 << 19)
+#define BP_SSE_N 32
+#define BP_NC1 64    // bpn1[1 + msb], bpn1[1 + 32 + lctx]: indices < 49
+#define BP_NC2 258   // bpn2[0], bpn2[1 + ctx1]: indices < 257
+#define BP_NW 42     // lmixref[8][3], lmixsig[8][2], finalmix[2]  (mixctx = state & 7: 8 of the 32 mixers are ever used)
+#define BP_DIVN 1024 // div_tbl entries reachable with the coder's counter limit (1000)
+
+struct BpJob {
+  const int32_t *buf;  // s2u residuals (non-negative), n entries
+  int32_t n, maxbpn;
+};
+
+__device__ __forceinline__ int bp_clamp(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ int bp_idiv32(int val, int s) { return val < 0 ? -(((-val) + (1 << (s - 1))) >> s) : (val + (1 << (s - 1))) >> s; }
+__device__ __forceinline__ long long bp_idiv64(long long val, int s) { return val < 0 ? -(((-val) + (1 << (s - 1))) >> s) : (val + (1 << (s - 1))) >> s; }
+
+// residuals of 64 buffers -> T[(block * maxn + s) * 64 + lane]
+__global__ __launch_bounds__(256) void k_bp_transpose(const BpJob *__restrict__ jobs, int nbuf, int maxn, int32_t *__restrict__ T) {
+  const int lane = threadIdx.x & 63, blk = blockIdx.y, b = blk * 64 + lane;
+  const int s0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+  if (b >= nbuf) {
+    for (int s = s0; s < s0 + 64 && s < maxn; s++) T[((size_t)blk * maxn + s) * 64 + lane] = 0;
+    return;
+  }
+  const BpJob j = jobs[b];
+  for (int s = s0; s < s0 + 64 && s < maxn; s++) T[((size_t)blk * maxn + s) * 64 + lane] = s < j.n ? j.buf[s] : 0;
+}
+
+// tables: fwd[32768] int16 | inv[4096] uint16 | sse init map[33] uint16 | tscale, xscale (2 x int32 at the end), as the host laid them out
+struct BpTables {
+  const int16_t *fwd;
+  const uint16_t *inv;
+  const uint16_t *sse_init;
+  int tscale, xscale;
+};
+
+__global__ __launch_bounds__(64) void k_bpsize(const BpJob *__restrict__ jobs, int nbuf, int maxn, int maxplanes, const int32_t *__restrict__ T,
+                                               uint8_t *__restrict__ msb_g, uint32_t *__restrict__ sse_g, uint8_t *__restrict__ lb_g,
+                                               BpTables tb, int32_t *__restrict__ sizes) {
+  __shared__ int16_t fwd[BP_PSCALE];
+  __shared__ uint16_t inv[1 << BP_DBITS];
+  __shared__ uint16_t divt[BP_DIVN];
+  __shared__ uint16_t c1[BP_NC1][64], c2[BP_NC2][64];
+  __shared__ int wts[BP_NW][64];
+  const int lane = threadIdx.x, blk = blockIdx.x, b = blk * 64 + lane;
+  for (int i = lane; i < BP_PSCALE; i += 64) fwd[i] = tb.fwd[i];
+  for (int i = lane; i < (1 << BP_DBITS); i += 64) inv[i] = tb.inv[i];
+  for (int i = lane; i < BP_DIVN; i += 64) divt[i] = (uint16_t)(BP_PSCALE / (i + 3));  // counter.h:38-50
+  for (int i = 0; i < BP_NC1; i++) c1[i][lane] = BP_PSCALE >> 1;
+  for (int i = 0; i < BP_NC2; i++) c2[i][lane] = BP_PSCALE >> 1;
+  for (int i = 0; i < BP_NW; i++) wts[i][lane] = 0;  // NMixLogistic::Init(0)
+  const bool live = b < nbuf;
+  const int n = live ? jobs[b].n : 0, mbp = live ? jobs[b].maxbpn : -1;
+  const int32_t *Tb = T + (size_t)blk * maxn * 64 + lane;
+  uint8_t *msb = msb_g + (size_t)blk * (maxn + 16) * 64 + lane;       // [s + 4][lane]: zero entries on either side
+  const int nctx = maxplanes * 32;
+  uint32_t *sse = sse_g + (size_t)blk * nctx * 66 * 64 + lane;         // [(ctx * 2 + lb) * 33 + q][lane]: p1 | counter << 16
+  uint8_t *lbp = lb_g + (size_t)blk * nctx * 64 + lane;
+  for (int s = 0; s < maxn + 16; s++) msb[(size_t)s * 64] = 0;
+  for (int e = 0; e < nctx * 66; e++) sse[(size_t)e * 64] = tb.sse_init[e % 33];  // SSENL ctor, sse.h:94-105
+  for (int e = 0; e < nctx; e++) lbp[(size_t)e * 64] = 0;
+  __syncthreads();
+  const int tscale = tb.tscale, xscale = tb.xscale;
+
+  auto dinv = [&](int x) -> int { return x < -(1 << (BP_DBITS - 1)) ? 0 : (x > (1 << (BP_DBITS - 1)) - 1 ? BP_PSCALE - 1 : (int)inv[x + (1 << (BP_DBITS - 1))]); };
+  auto lc16 = [&](uint16_t *c, int bit, int L) {  // LinearCounter16::update(bit, L), counter.h:30-35
+    const int p = *c, err = (bit << BP_PBITS) - p;
+    *c = (uint16_t)bp_clamp(p + bp_idiv32(L * err, BP_PBITS), 1, BP_PSCALEm);
+  };
+  auto lcl = [&](uint32_t *e, int bit, int limit) {  // LinearCounterLimit::update, counter.h:57-65
+    uint32_t v = *e;
+    int p1 = (int)(v & 0xffffu), cnt = (int)(v >> 16);
+    if (cnt < limit) cnt++;
+    const int dp = bit ? ((BP_PSCALE - p1) * (int)divt[cnt]) >> BP_PBITS : -((p1 * (int)divt[cnt]) >> BP_PBITS);
+    p1 = bp_clamp(p1 + dp, 1, BP_PSCALEm);
+    *e = (uint32_t)p1 | ((uint32_t)cnt << 16);
+  };
+  // RangeCoderSH (range.cpp:52-90), counting the bytes it would put
+  uint32_t range = 0xFFFFFFFFu, ffnum = 0, cache = 0;
+  unsigned long long lowc = 0;
+  int pos = 0;
+  auto shift_low = [&]() {
+    const uint32_t carry = (uint32_t)(lowc >> 32), low = (uint32_t)lowc;
+    if (low < 0xFF000000u || carry) { pos += 1 + (int)ffnum; ffnum = 0; cache = low >> 24; }
+    else ffnum++;
+    lowc = (unsigned long long)(low << 8);
+  };
+  (void)cache;
+
+  int topbpn = mbp;  // the wave walks the planes of its deepest buffer; a lane joins at its own maxbpn
+  for (int o = 32; o; o >>= 1) topbpn = max(topbpn, __shfl_xor(topbpn, o));
+  int topn = n;
+  for (int o = 32; o; o >>= 1) topn = max(topn, __shfl_xor(topn, o));
+  for (int bpn = topbpn; bpn >= 0; bpn--) {
+    const bool plane_on = live && bpn <= mbp;
+    uint32_t state = 0;
+    // sliding windows: residuals s-2..s+2, msb s-4..s+4 (the entries beyond the buffer's ends read as 0: vle.cpp:19-28, :36-39)
+    int a_m2 = 0, a_m1 = 0, a_0 = 0, a_p1 = 0, a_p2 = 0;
+    int m[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) m[k] = 0;
+    if (topn > 0) { a_0 = Tb[0]; a_p1 = topn > 1 ? Tb[64] : 0; a_p2 = topn > 2 ? Tb[128] : 0; }
+#pragma unroll
+    for (int k = 4; k < 9; k++) m[k] = msb[(size_t)(k) * 64];  // m[4] = msb[s = 0] ... m[8] = msb[s = 4]
+    for (int s = 0; s < topn; s++) {
+      if (plane_on && s < n) {
+        const int bit = (a_0 >> bpn) & 1;
+        const int mixctx = (int)(state & 7);
+        const int mymsb = m[4];
+        const bool sig = mymsb != 0;
+        uint16_t *pc0 = &c2[0][lane], *pc1, *pc2 = nullptr;
+        int *w;
+        int nin;
+        if (sig) {  // PredictRef, vle.cpp:32-60
+          const int lval = a_m1, lval2 = a_m2;
+          const int nval = (s < n - 1) ? a_p1 : 0, nval2 = (s < n - 2) ? a_p2 : 0;
+          const int tval = a_0 >> (bpn + 1), tval1 = tval << 1;
+          int lctx = 0;
+          if ((lval >> bpn) > tval1) lctx += 1;
+          if ((nval >> (bpn + 1)) > tval) lctx += 2;
+          if ((lval2 >> bpn) > tval1) lctx += 4;
+          if ((nval2 >> (bpn + 1)) > tval) lctx += 8;
+          pc1 = &c1[1 + mymsb][lane];
+          pc2 = &c1[1 + 32 + lctx][lane];
+          w = &wts[mixctx * 3][lane];
+          nin = 3;
+        } else {  // PredictSig, vle.cpp:71-92
+          int ctx1 = 0;
+          if (m[3]) ctx1 += 1;
+          if (m[5] && s + 1 <= n - 1) ctx1 += 2;
+          if (m[2]) ctx1 += 4;
+          if (m[6] && s + 2 <= n - 1) ctx1 += 8;
+          if (m[1]) ctx1 += 16;
+          if (m[7] && s + 3 <= n - 1) ctx1 += 32;
+          if (m[0]) ctx1 += 64;
+          if (m[8] && s + 4 <= n - 1) ctx1 += 128;
+          pc1 = &c2[1 + ctx1][lane];
+          w = &wts[24 + mixctx * 2][lane];
+          nin = 2;
+        }
+        // NMixLogistic::Predict, mixer.h:73-84
+        const int x0 = fwd[*pc0], x1 = fwd[*pc1], x2 = sig ? (int)fwd[*pc2] : 0;
+        long long sum = (long long)(w[0] * x0) + (long long)(w[64] * x1);
+        if (sig) sum += (long long)(w[128] * x2);
+        const int pd = bp_clamp(dinv((int)bp_idiv64(sum, BP_WBITS)), 1, BP_PSCALEm);
+        // SSENL::Predict, sse.h:106-118  (context (bpn << 5) + msb, vle.cpp:98)
+        const int ctx = (bpn << 5) + mymsb;
+        const int lb = lbp[(size_t)ctx * 64];
+        int pq = (int)fwd[pd] + tscale;
+        pq = pq < 0 ? 0 : (pq > 2 * tscale ? 2 * tscale : pq);
+        const int q = pq / xscale, pmod = pq - q * xscale;
+        uint32_t *e0 = &sse[(size_t)((ctx * 2 + lb) * 33 + q) * 64], *e1 = e0 + 64;
+        const int pl = (int)(*e0 & 0xffffu), ph = (int)(*e1 & 0xffffu);
+        const int ps = bp_clamp((pl * (xscale - pmod) + ph * pmod) / xscale, 1, BP_PSCALEm);
+        // finalmix[0].Predict({sse, p1}), vle.cpp:100-102
+        int *wf = &wts[40][lane];
+        const int y0 = fwd[ps], y1 = fwd[pd];
+        const long long fs = (long long)(wf[0] * y0) + (long long)(wf[64] * y1);
+        const int pf = bp_clamp(dinv((int)bp_idiv64(fs, BP_WBITS)), 1, BP_PSCALEm);
+        // RangeCoderSH::EncodeBitOne, range.cpp:65-70
+        const uint32_t rnew = (uint32_t)(((unsigned long long)range * ((uint32_t)(BP_PSCALE - pf) << (32 - BP_PBITS))) >> 32);
+        if (bit) { range -= rnew; lowc += rnew; } else range = rnew;
+        while (range < 0x01000000u) { range <<= 8; shift_low(); }
+        // UpdateRef / UpdateSig (vle.cpp:62-69, :94-101): counters at rate 350, mixer at 800
+        lc16(pc0, bit, 350);
+        lc16(pc1, bit, 350);
+        if (sig) lc16(pc2, bit, 350);
+        {
+          const int err = (bit << BP_PBITS) - pd;
+          w[0] = bp_clamp(w[0] + bp_idiv32(bp_idiv32(x0 * err, BP_DBITS) * 800, BP_DBITS), -BP_WRANGE, BP_WRANGE - 1);
+          w[64] = bp_clamp(w[64] + bp_idiv32(bp_idiv32(x1 * err, BP_DBITS) * 800, BP_DBITS), -BP_WRANGE, BP_WRANGE - 1);
+          if (sig) w[128] = bp_clamp(w[128] + bp_idiv32(bp_idiv32(x2 * err, BP_DBITS) * 800, BP_DBITS), -BP_WRANGE, BP_WRANGE - 1);
+        }
+        state = (state << 1) + (sig ? 0u : 1u);
+        // UpdateSSE (vle.cpp:104-108): both bins at limit 1000, lb = bit; final mixer at 300
+        lcl(e0, bit, 1000);
+        lcl(e1, bit, 1000);
+        lbp[(size_t)ctx * 64] = (uint8_t)bit;
+        {
+          const int err = (bit << BP_PBITS) - pf;
+          wf[0] = bp_clamp(wf[0] + bp_idiv32(bp_idiv32(y0 * err, BP_DBITS) * 300, BP_DBITS), -BP_WRANGE, BP_WRANGE - 1);
+          wf[64] = bp_clamp(wf[64] + bp_idiv32(bp_idiv32(y1 * err, BP_DBITS) * 300, BP_DBITS), -BP_WRANGE, BP_WRANGE - 1);
+        }
+        if (!sig && bit) { m[4] = bpn; msb[(size_t)(s + 4) * 64] = (uint8_t)bpn; }  // vle.cpp:132
+      }
+      // slide the windows
+      a_m2 = a_m1; a_m1 = a_0; a_0 = a_p1; a_p1 = a_p2;
+      a_p2 = (s + 3 < topn) ? Tb[(size_t)(s + 3) * 64] : 0;
+#pragma unroll
+      for (int k = 0; k < 8; k++) m[k] = m[k + 1];
+      m[8] = msb[(size_t)(s + 9) * 64];  // msb[s + 1 + 4], stored at [s + 5 + 4]; the array has 4 zero entries past maxn
+    }
+  }
+  if (live) {
+    for (int i = 0; i < 5; i++) shift_low();  // RangeCoderSH::Stop, range.cpp:60-63
+    sizes[b] = pos;
+  }
+}

@@ -1505,6 +1505,7 @@ __global__ __launch_bounds__(256) void k_sumkat(const double *__restrict__ x, do
 }
 
 #include "unpredict.h"
+#include "bitplane.h"
 
 // ------------------------------------------------------------------------------------------
 // host-callable launchers (sacopt.cpp is compiled by the host compiler pass of the same TU set)
@@ -1648,6 +1649,17 @@ extern "C" int sacopt_launch_sumkat(int nterms, const double *x, int count, doub
   else if (nterms == 48) hipLaunchKernelGGL((k_sumkat<48>), dim3(count), dim3(256), 0, st, x, out);
   else if (nterms == 12) hipLaunchKernelGGL((k_sumkat<12>), dim3(count), dim3(256), 0, st, x, out);
   else return 1;
+  return hipGetLastError() != hipSuccess;
+}
+// payload sizes of the host's bit-plane coder for nbuf residual buffers (bitplane.h). T / msb / sse / lb: scratch.
+extern "C" int sacopt_launch_bpsize(const BpJob *jobs, int nbuf, int maxn, int maxplanes, int32_t *T, uint8_t *msb, uint32_t *sse, uint8_t *lb,
+                                    const int16_t *fwd, const uint16_t *inv, const uint16_t *sse_init, int tscale, int xscale, int32_t *sizes,
+                                    hipStream_t st) {
+  if (nbuf <= 0) return 0;
+  const int nblk = (nbuf + 63) / 64;
+  if (maxn > 0) hipLaunchKernelGGL(k_bp_transpose, dim3((maxn + 255) / 256, nblk), dim3(256), 0, st, jobs, nbuf, maxn, T);
+  BpTables tb = {fwd, inv, sse_init, tscale, xscale};
+  hipLaunchKernelGGL(k_bpsize, dim3(nblk), dim3(64), 0, st, jobs, nbuf, maxn, maxplanes, T, msb, sse, lb, tb, sizes);
   return hipGetLastError() != hipSuccess;
 }
 extern "C" int sacopt_launch_map(const MapJob *jobs, int njobs, int max_numsamples, int max_n, hipStream_t st) {

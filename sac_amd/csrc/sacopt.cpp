@@ -34,6 +34,9 @@ int sacopt_launch_chol(const LpcJob *job, int n, int fast, hipStream_t st);
 int sacopt_launch_sumkat(int nterms, const double *x, int count, double *out, hipStream_t st);
 int sacopt_launch_map(const MapJob *jobs, int njobs, int max_numsamples, int max_n, hipStream_t st);
 int sacopt_launch_unpredict(int type, const UnJob *jobs, int njobs, const uint16_t *tab, int bits, hipStream_t st);
+struct BpJob { const int32_t *buf; int32_t n, maxbpn; };
+int sacopt_launch_bpsize(const BpJob *jobs, int nbuf, int maxn, int maxplanes, int32_t *T, uint8_t *msb, uint32_t *sse, uint8_t *lb,
+                         const int16_t *fwd, const uint16_t *inv, const uint16_t *sse_init, int tscale, int xscale, int32_t *sizes, hipStream_t st);
 int sacopt_noalloc_scratch(int device, void **ptr, size_t *stage_bytes, size_t *ctl_doubles, int *max_n);
 int sacopt_launch_cost_noalloc(const int32_t *e, int n, double *ctl, const int *pow2_bits, hipStream_t st);
 }
@@ -69,6 +72,10 @@ struct sacopt_ctx {
   int lms_launches = 0;
   long long lms_units = 0;  // stereo samples processed by the timed launches
   int timed_variant = 1;    // which (1280,640) kernel's launches are timed: 1 = k_lms1c (calls of <= 20 frames), 0 = the two-channel kernel
+  // LogDomain tables of the host's bit-plane coder (src/model/domain.h:6-57), tabulated with THIS host's libm at create
+  int16_t *d_bp_fwd = nullptr;
+  uint16_t *d_bp_inv = nullptr, *d_bp_sse = nullptr;
+  int bp_tscale = 0, bp_xscale = 0;
   // residual buffers of the last sacopt_get_costs call (still in the arena), for sacopt_recost_last
   struct Kept {
     bool valid = false;
@@ -310,6 +317,25 @@ extern "C" int sacopt_create(int device, const float *rsqrt_tab, int rsqrt_bits,
   pw[31] = 31;
   if (hipMalloc(&c->d_pow2, sizeof(pw)) != hipSuccess) return fail("hipMalloc failed");
   if (hipMemcpy(c->d_pow2, pw, sizeof(pw), hipMemcpyHostToDevice) != hipSuccess) return fail("upload failed");
+  {  // stretch / squash tables of the bit-plane coder's logistic mixing (domain.h:12-23) and the SSE stage's initial map (sse.h:94-105)
+    std::vector<int16_t> fwd(1 << 15);
+    std::vector<uint16_t> inv(1 << 12), sse(33);
+    const int PS = 1 << 15;
+    for (int i = 0; i < PS; i++) fwd[i] = (int16_t)floor(log((i + 0.5) / (PS - i - 0.5)) * 256. + 0.5);
+    for (int i = -2048; i <= 2047; i++) inv[i + 2048] = (uint16_t)floor((double)PS / (1.0 + exp(-(double)i / 256.)));
+    c->bp_tscale = fwd[PS - 1];
+    c->bp_xscale = (2 * c->bp_tscale) / 31;
+    if (c->bp_xscale == 0) c->bp_xscale = 1;
+    for (int i = 0; i <= 32; i++) {
+      const int x = i * c->bp_xscale - c->bp_tscale;
+      sse[i] = x < -2048 ? 0 : (x > 2047 ? PS - 1 : inv[x + 2048]);
+    }
+    if (hipMalloc(&c->d_bp_fwd, fwd.size() * 2) != hipSuccess || hipMalloc(&c->d_bp_inv, inv.size() * 2) != hipSuccess ||
+        hipMalloc(&c->d_bp_sse, 33 * 2) != hipSuccess) return fail("hipMalloc failed");
+    if (hipMemcpy(c->d_bp_fwd, fwd.data(), fwd.size() * 2, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(c->d_bp_inv, inv.data(), inv.size() * 2, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(c->d_bp_sse, sse.data(), 33 * 2, hipMemcpyHostToDevice) != hipSuccess) return fail("upload failed");
+  }
   if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) return fail("hipEventCreate failed");
   {  // this device's copy of the static scratch (hipGetSymbolAddress with the device current; the array's name is no address)
     void *p = nullptr;
@@ -331,6 +357,9 @@ extern "C" void sacopt_destroy(sacopt_ctx *c) {
   for (auto &b : c->pins) (void)hipHostFree(b.p);
   if (c->d_tab) (void)hipFree(c->d_tab);
   if (c->d_pow2) (void)hipFree(c->d_pow2);
+  if (c->d_bp_fwd) (void)hipFree(c->d_bp_fwd);
+  if (c->d_bp_inv) (void)hipFree(c->d_bp_inv);
+  if (c->d_bp_sse) (void)hipFree(c->d_bp_sse);
   for (hipEvent_t e : c->pipe_ev) (void)hipEventDestroy(e);
   if (c->sA) (void)hipStreamDestroy(c->sA);
   if (c->sB) (void)hipStreamDestroy(c->sB);
@@ -1628,6 +1657,49 @@ extern "C" int sacopt_cost_golomb_noalloc(sacopt_ctx *c, const int32_t *buf, int
   if (state_inout) *state_inout = res[0];
   *cost = res[1];
   return 0;
+}
+
+// ------------------------------------------------------------------------------------------ bit-plane coder size
+extern "C" int sacopt_coded_sizes(sacopt_ctx *c, int nbuf, const int32_t *const *s2u, const int32_t *n, const int32_t *maxbpn, int32_t *sizes) {
+  if (!c) return 1;
+  if (begin_call(c)) return 1;
+  if (nbuf < 0 || (nbuf && (!s2u || !n || !maxbpn || !sizes))) { c->err = "bad arguments"; return 1; }
+  if (!nbuf) return 0;
+  int maxn = 0, maxplanes = 1;
+  size_t host_bytes = 0;
+  for (int b = 0; b < nbuf; b++) {
+    if (n[b] < 0 || (n[b] && !s2u[b])) { c->err = "bad buffer"; return 1; }
+    if (maxbpn[b] < 0 || maxbpn[b] > 30) { c->err = "maxbpn out of range (0..30)"; return 1; }
+    maxn = n[b] > maxn ? n[b] : maxn;
+    maxplanes = maxbpn[b] + 1 > maxplanes ? maxbpn[b] + 1 : maxplanes;
+    host_bytes += ((size_t)n[b] * 4 + 255) & ~(size_t)255;
+  }
+  const size_t nblk = (nbuf + 63) / 64, nctx = (size_t)maxplanes * 32;
+  const size_t need = host_bytes + nblk * ((size_t)maxn * 256 + ((size_t)maxn + 16) * 64 + nctx * 66 * 256 + nctx * 64) + (size_t)nbuf * (sizeof(BpJob) + 8) + (1 << 16);
+  if (arena_reserve(c, need)) return 1;
+  HIPCK(c, hipEventRecord(c->ev0, c->st));
+  std::vector<BpJob> jobs(nbuf);
+  for (int b = 0; b < nbuf; b++) {
+    jobs[b].n = n[b]; jobs[b].maxbpn = maxbpn[b]; jobs[b].buf = nullptr;
+    if (n[b] && to_dev(c, s2u[b], (size_t)n[b], &jobs[b].buf)) return 1;
+  }
+  BpJob *dj;
+  if (upload(c, jobs, &dj)) return 1;
+  int32_t *T = arena_alloc<int32_t>(c, nblk * (size_t)(maxn ? maxn : 1) * 64);
+  uint8_t *msb = arena_alloc<uint8_t>(c, nblk * ((size_t)maxn + 16) * 64);
+  uint32_t *sse = arena_alloc<uint32_t>(c, nblk * nctx * 66 * 64);
+  uint8_t *lb = arena_alloc<uint8_t>(c, nblk * nctx * 64);
+  int32_t *dsz = arena_alloc<int32_t>(c, nbuf);
+  if (!T || !msb || !sse || !lb || !dsz) { c->err = "device arena exhausted"; return 1; }
+  hipEvent_t a, b2;
+  HIPCK(c, hipEventCreate(&a));
+  HIPCK(c, hipEventCreate(&b2));
+  HIPCK(c, hipEventRecord(a, c->st));
+  if (sacopt_launch_bpsize(dj, nbuf, maxn, maxplanes, T, msb, sse, lb, c->d_bp_fwd, c->d_bp_inv, c->d_bp_sse, c->bp_tscale, c->bp_xscale, dsz, c->st)) { c->err = "k_bpsize launch failed"; return 1; }
+  HIPCK(c, hipEventRecord(b2, c->st));
+  c->lms_ev.push_back({a, b2});
+  HIPCK(c, hipMemcpyAsync(sizes, dsz, (size_t)nbuf * 4, hipMemcpyDeviceToHost, c->st));
+  return end_timing(c);
 }
 
 extern "C" int sacopt_cost_meanrms(sacopt_ctx *c, const int32_t *buf, int n, double *cost) {

@@ -58,6 +58,7 @@ def lib():
         L.sacopt_encode_frames.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.sacopt_unpredict_stereo_frames.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.sacopt_cost_golomb.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.sacopt_coded_sizes.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.sacopt_cost_golomb_noalloc.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.sacopt_cost_meanrms.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.sacopt_lms_pair.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p,
@@ -73,7 +74,7 @@ def lib():
 
 
 EXPORTS = ["sacopt_create", "sacopt_destroy", "sacopt_last_error", "sacopt_probe_rsqrt", "sacopt_base_profile",
-           "sacopt_predict_stereo_frames", "sacopt_get_costs", "sacopt_recost_last", "sacopt_optimize_frames", "sacopt_encode_frames", "sacopt_unpredict_stereo_frames", "sacopt_cost_golomb", "sacopt_cost_golomb_noalloc",
+           "sacopt_predict_stereo_frames", "sacopt_get_costs", "sacopt_recost_last", "sacopt_optimize_frames", "sacopt_encode_frames", "sacopt_unpredict_stereo_frames", "sacopt_cost_golomb", "sacopt_cost_golomb_noalloc", "sacopt_coded_sizes",
            "sacopt_cost_meanrms", "sacopt_lms_pair", "sacopt_lpc3_pair", "sacopt_rls_run", "sacopt_chol_solve", "sacopt_serial_sum",
            "sacopt_cascade_trace", "sacopt_last_timing"]
 
@@ -319,6 +320,21 @@ class Context:
             buf, n = buf
         self._ck(lib().sacopt_cost_golomb_noalloc(self._h, _p(buf), n, _p(st), _p(cost)))
         return float(cost[0]), float(st[0])
+
+    def coded_sizes(self, bufs, maxbpn):
+        """sacopt_coded_sizes: bufs = list of numpy int32 arrays (s2u residuals) or (device pointer, n) tuples."""
+        nb = len(bufs)
+        keep, ptrs, ns = [], (C.c_void_p * max(nb, 1))(), np.zeros(nb, np.int32)
+        for i, b in enumerate(bufs):
+            if isinstance(b, np.ndarray):
+                a = np.ascontiguousarray(b, dtype=np.int32); keep.append(a)
+                ptrs[i] = a.ctypes.data if len(a) else None; ns[i] = len(a)
+            else:
+                ptrs[i] = int(b[0]); ns[i] = int(b[1])
+        mb = np.ascontiguousarray(maxbpn, dtype=np.int32)
+        out = np.zeros(nb, np.int32)
+        self._ck(lib().sacopt_coded_sizes(self._h, nb, ptrs, _p(ns), _p(mb), _p(out)))
+        return out
 
     def cost_meanrms(self, buf):
         buf = np.ascontiguousarray(buf, dtype=np.int32)

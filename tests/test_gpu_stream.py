@@ -159,3 +159,32 @@ def test_parameter_stream_round_trip(prof):
         dec = c.unpredict(prof, dec_in, coefs=np.stack(coefs))
         got_l = np.concatenate([v[0] for v in dec]); got_r = np.concatenate([v[1] for v in dec])
         assert np.array_equal(got_l, L) and np.array_equal(got_r, R)
+
+
+# ---------------------------------------------------------------- the host coder's payload size on the device
+def test_coded_sizes_vs_restated_coder(oracle):
+    # sacopt_coded_sizes = the number of bytes BitplaneCoder::Encode + RangeCoderSH write (codec.cpp:237-247), one coder
+    # per lane, against oracle/sac_coder.c (itself byte-identical to the reference's Encode():
+    # test_oracle_vs_ref.py::test_bitplane_coder_bytes). Ragged batch: three profiles' residuals, different lengths and
+    # plane counts in one wave, a 24-bit pair, silence, a single sample, an empty buffer, more buffers than one wave holds.
+    import ctypes as C
+    bufs, mb = [], []
+    for prof, seed, n in ((0, 71, 5000), (1, 72, 3001), (2, 73, 4096)):
+        L, R = stereo_clip(seed, n)
+        r = oracle.predict(prof, L, R, maps=True)
+        bufs += [r["u0"], r["u1"], r["m0"]]; mb += [r["maxbpn"][0], r["maxbpn"][1], r["maxbpn"][2]]
+    L, R = stereo_clip(74, 2500, rate=96000, bits=24)
+    r = oracle.predict(2, L, R, maps=True)
+    bufs += [r["u0"], r["u1"]]; mb += [r["maxbpn"][0], r["maxbpn"][1]]
+    bufs += [np.zeros(700, np.int32), np.array([5], np.int32), np.zeros(0, np.int32), np.array([0, 0, 1, 0], np.int32)]
+    mb += [0, 2, 0, 0]
+    rs = np.random.RandomState(3)
+    for k in range(70):   # a second wave, short random buffers
+        nb = int(rs.randint(1, 400)); top = int(rs.randint(0, 12))
+        bufs.append(rs.randint(0, 1 << (top + 1), nb).astype(np.int32)); mb.append(top)
+    with sacopt.Context(0) as c:
+        got = c.coded_sizes(bufs, mb)
+    for i, (b, m) in enumerate(zip(bufs, mb)):
+        b = np.ascontiguousarray(b, dtype=np.int32)
+        want = oracle.lib.oracle_encode_mono_normal(b.ctypes.data_as(C.c_void_p), C.c_int(len(b)), C.c_int(int(m)), None, C.c_int(0))
+        assert got[i] == want, (i, len(b), m, got[i], want)
