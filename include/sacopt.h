@@ -79,6 +79,17 @@ int sacopt_predict_stereo_frames(sacopt_ctx *ctx, int profile, int nframes, cons
                                  const int32_t *from, const int32_t *n, const double *coefs,
                                  sacopt_residuals *out);
 
+/* ---- CostFunction (src/codec.h:10-15): what GetCost / Optimize evaluate a candidate's residuals with ----------------------
+ * GOLOMB   CostGolomb  (src/codec.cpp:315-339): the one FrameCoder::Optimize instantiates (:364); running mean carried from call to call
+ * MEANRMS  CostMeanRMS (src/codec.cpp:302-312): the reference's other implementation (mean |e|), instantiated nowhere
+ * BITPLANE no counterpart in the reference: 8 x bytes / samples of the payload the host's bit-plane coder
+ *          would write for the buffer (sacopt_coded_sizes below; plain variant, a fresh coder per buffer as Encode() has)
+ * The choice holds for the context until changed; default GOLOMB. */
+#define SACOPT_COST_GOLOMB 0
+#define SACOPT_COST_MEANRMS 1
+#define SACOPT_COST_BITPLANE 2
+int sacopt_set_cost_function(sacopt_ctx *ctx, int which);
+
 /* ---- FrameCoder::GetCost  src/codec.cpp:341-352  (+ CostGolomb::Calc :315-339) ------------- */
 /* Evaluates, for every frame, `ncand` candidate coefficient vectors (cand_coefs[(f*ncand+c)*ncoef..])
  * over the window [from[f], from[f]+n[f]) and returns costs[f*ncand+c] =

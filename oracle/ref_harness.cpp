@@ -183,15 +183,27 @@ int ref_optimize(int profile, const int32_t *s0, const int32_t *s1, int numsampl
 // CostGolomb instance, recording every (coef, x, cost) triple. ncoef_loop lets non-high
 // profiles run the documented deviation (loop over coefs.size() instead of 8).
 // trace: rows of 3 doubles {coef(-1 for the baseline call), x, cost}; returns number of rows.
+static int optimize_trace_cf(CostFunction &CostFunc, int profile, const int32_t *s0, const int32_t *s1, int numsamples,
+                             int ncoef_loop, double *best, double *trace, int max_rows);
 int ref_optimize_trace(int profile, const int32_t *s0, const int32_t *s1, int numsamples,
                        int ncoef_loop, double *best, double *trace, int max_rows) {
+  CostGolomb cf;
+  return optimize_trace_cf(cf, profile, s0, s1, numsamples, ncoef_loop, best, trace, max_rows);
+}
+// ... with the reference's OTHER CostFunction, CostMeanRMS (codec.cpp:302-312; instantiated nowhere upstream)
+int ref_optimize_trace_meanrms(int profile, const int32_t *s0, const int32_t *s1, int numsamples,
+                               int ncoef_loop, double *best, double *trace, int max_rows) {
+  CostMeanRMS cf;
+  return optimize_trace_cf(cf, profile, s0, s1, numsamples, ncoef_loop, best, trace, max_rows);
+}
+static int optimize_trace_cf(CostFunction &CostFunc, int profile, const int32_t *s0, const int32_t *s1, int numsamples,
+                             int ncoef_loop, double *best, double *trace, int max_rows) {
   CoutMute mute;
   FrameCoder fc(2, numsamples, profile);
   load_frame(fc, s0, s1, numsamples);
   SacProfile prof = fc.baseprofile;
   int samples_to_optimize = numsamples / 8;
   int start = (numsamples - samples_to_optimize) / 2;
-  CostGolomb CostFunc;
   int rows = 0;
   double best_cost = fc.GetCost(prof, &CostFunc, 0, prof.coefs[0].vdef, start, samples_to_optimize);
   if (rows < max_rows) { trace[3 * rows] = -1; trace[3 * rows + 1] = prof.coefs[0].vdef; trace[3 * rows + 2] = best_cost; rows++; }

@@ -736,8 +736,23 @@ double oracle_cost_golomb(const int32_t *buf, int n, double *state) { /* codec.c
 }
 
 /* ------------------------------------------------------------------ Optimize / GetCost (src/codec.cpp:341-408) */
+int oracle_encode_mono_normal(const int32_t *s2u, int numsamples, int maxbpn, unsigned char *out, int cap); /* sac_coder.c */
+/* cost_fn: 0 CostGolomb (what the reference's Optimize uses, codec.cpp:364), 1 CostMeanRMS (codec.cpp:302-312), 2 bits per
+ * sample of the bit-plane coder's payload (no reference counterpart) */
+int oracle_optimize_cf(int profile, const double *prof_in, int ncoef_loop, const int32_t *s0, const int32_t *s1,
+                       int numsamples, int cost_fn, double *best, double *trace, int max_rows);
 int oracle_optimize(int profile, const double *prof_in, int ncoef_loop, const int32_t *s0, const int32_t *s1,
                     int numsamples, double *best, double *trace, int max_rows) {
+  return oracle_optimize_cf(profile, prof_in, ncoef_loop, s0, s1, numsamples, 0, best, trace, max_rows);
+}
+static double cost_bitplane(const int32_t *u, int n) {
+  if (!n) return 0.;
+  int32_t mx = 0;
+  for (int i = 0; i < n; i++) if (u[i] > mx) mx = u[i];
+  return 8. * (double)oracle_encode_mono_normal(u, n, ilog2(mx), 0, 0) / (double)n;
+}
+int oracle_optimize_cf(int profile, const double *prof_in, int ncoef_loop, const int32_t *s0, const int32_t *s1,
+                       int numsamples, int cost_fn, double *best, double *trace, int max_rows) {
   double prof[8 * 3], c[8];
   int nc = oracle_base_profile(profile, prof);
   if (!nc) return -1;
@@ -746,15 +761,18 @@ int oracle_optimize(int profile, const double *prof_in, int ncoef_loop, const in
   const int n = numsamples / 8;           /* codec.cpp:356-357 */
   const int start = (numsamples - n) / 2; /* codec.cpp:359 */
   int32_t *e0 = (int32_t *)malloc(sizeof(int32_t) * (n ? n : 1)), *e1 = (int32_t *)malloc(sizeof(int32_t) * (n ? n : 1));
+  int32_t *u0 = (int32_t *)malloc(sizeof(int32_t) * (n ? n : 1)), *u1 = (int32_t *)malloc(sizeof(int32_t) * (n ? n : 1));
   double mean = 0.; /* one CostGolomb instance, never reset (codec.cpp:364) */
   int rows = 0;
 #define GETCOST(coef, x, dst)                                                                     \
   do {                                                                                            \
     for (int q = 0; q < nc; q++) c[q] = prof[3 * q + 2];                                          \
     c[coef] = (x);                                                                                \
-    oracle_predict_stereo_frame(profile, c, s0, s1, numsamples, start, n, e0, e1, 0, 0, 0, 0, 0); \
-    double c1 = oracle_cost_golomb(e0, n, &mean);                                                 \
-    double c2 = oracle_cost_golomb(e1, n, &mean);                                                 \
+    oracle_predict_stereo_frame(profile, c, s0, s1, numsamples, start, n, e0, e1, u0, u1, 0, 0, 0); \
+    double c1, c2;                                                                                \
+    if (cost_fn == 1) { c1 = oracle_cost_meanrms(e0, n); c2 = oracle_cost_meanrms(e1, n); }      \
+    else if (cost_fn == 2) { c1 = cost_bitplane(u0, n); c2 = cost_bitplane(u1, n); }             \
+    else { c1 = oracle_cost_golomb(e0, n, &mean); c2 = oracle_cost_golomb(e1, n, &mean); }        \
     dst = (c1 + c2) / 2.;                                                                         \
   } while (0)
   double best_cost;
@@ -777,7 +795,7 @@ int oracle_optimize(int profile, const double *prof_in, int ncoef_loop, const in
   }
 #undef GETCOST
   for (int i = 0; i < nc; i++) best[i] = prof[3 * i + 2];
-  free(e0); free(e1);
+  free(e0); free(e1); free(u0); free(u1);
   return rows;
 }
 

@@ -72,5 +72,8 @@ void oracle_remap_map(const int32_t *src, int n, const int32_t *pred, const int3
 int oracle_encode_mono_normal(const int32_t *s2u, int numsamples, int maxbpn, unsigned char *out, int cap);
 int oracle_encode_mono_mapped(const int32_t *s2u_map, int numsamples, int maxbpn_map, const unsigned char *used, unsigned char *out, int cap);
 
+int oracle_optimize_cf(int profile, const double *prof_in, int ncoef_loop, const int32_t *s0, const int32_t *s1,
+                       int numsamples, int cost_fn, double *best, double *trace, int max_rows);
+
 #endif
 

@@ -1381,6 +1381,27 @@ __global__ __launch_bounds__(64) void k_cseg_fin(const int32_t *__restrict__ e, 
   }
 }
 
+// CostMeanRMS::Calc (codec.cpp:302-312) for a list of buffers: blockIdx.x = buffer; sum of |e| in integers (exact), / n
+__global__ __launch_bounds__(256) void k_meanrms_batch(const int32_t *const *__restrict__ bufs, const int32_t *__restrict__ ns, double *__restrict__ out) {
+  __shared__ long long red[256];
+  const int32_t *e = bufs[blockIdx.x];
+  const int n = ns[blockIdx.x];
+  long long s = 0;
+  for (int i = threadIdx.x; i < n; i += 256) { const int v = e[i]; s += v < 0 ? -(long long)v : v; }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    long long tot = 0;
+    for (int i = 0; i < 256; i++) tot += red[i];
+    out[blockIdx.x] = n ? (double)tot / (double)n : 0.;
+  }
+}
+// out[i] = *ptrs[i] (the per-chain maxima of the s2u residuals, scattered over the arena)
+__global__ void k_gather_i32(const int32_t *const *__restrict__ ptrs, int n, int32_t *__restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = *ptrs[i];
+}
+
 // single buffer variant used by sacopt_cost_golomb / meanrms
 __global__ void k_meanrms(const int32_t *e, int n, double *out) {
   // CostMeanRMS::Calc (codec.cpp:302-312): sum of |e| as integers (exact in FP64), / n
@@ -1628,6 +1649,16 @@ extern "C" int sacopt_launch_cost_noalloc(const int32_t *e, int n, double *ctl, 
   if (nseg > 1) hipLaunchKernelGGL(k_cseg_tail, dim3(nseg - 1), dim3(64), 0, st, e, n, ctl, pow2_bits);
   hipLaunchKernelGGL(k_cseg_par, dim3(nseg), dim3(64), 0, st, e, n, nseg, ctl, pow2_bits);
   hipLaunchKernelGGL(k_cseg_fin, dim3(1), dim3(64), 0, st, e, n, nseg, ctl, pow2_bits);
+  return hipGetLastError() != hipSuccess;
+}
+extern "C" int sacopt_launch_meanrms_batch(const int32_t *const *bufs, const int32_t *ns, int nbuf, double *out, hipStream_t st) {
+  if (nbuf <= 0) return 0;
+  hipLaunchKernelGGL(k_meanrms_batch, dim3(nbuf), dim3(256), 0, st, bufs, ns, out);
+  return hipGetLastError() != hipSuccess;
+}
+extern "C" int sacopt_launch_gather_i32(const int32_t *const *ptrs, int n, int32_t *out, hipStream_t st) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(k_gather_i32, dim3((n + 255) / 256), dim3(256), 0, st, ptrs, n, out);
   return hipGetLastError() != hipSuccess;
 }
 extern "C" int sacopt_launch_meanrms(const int32_t *e, int n, double *out, hipStream_t st) {

@@ -37,6 +37,8 @@ int sacopt_launch_unpredict(int type, const UnJob *jobs, int njobs, const uint16
 struct BpJob { const int32_t *buf; int32_t n, maxbpn; };
 int sacopt_launch_bpsize(const BpJob *jobs, int nbuf, int maxn, int maxplanes, int32_t *T, uint8_t *msb, uint32_t *sse, uint8_t *lb,
                          const int16_t *fwd, const uint16_t *inv, const uint16_t *sse_init, int tscale, int xscale, int32_t *sizes, hipStream_t st);
+int sacopt_launch_meanrms_batch(const int32_t *const *bufs, const int32_t *ns, int nbuf, double *out, hipStream_t st);
+int sacopt_launch_gather_i32(const int32_t *const *ptrs, int n, int32_t *out, hipStream_t st);
 int sacopt_noalloc_scratch(int device, void **ptr, size_t *stage_bytes, size_t *ctl_doubles, int *max_n);
 int sacopt_launch_cost_noalloc(const int32_t *e, int n, double *ctl, const int *pow2_bits, hipStream_t st);
 }
@@ -77,13 +79,19 @@ struct sacopt_ctx {
   uint16_t *d_bp_inv = nullptr, *d_bp_sse = nullptr;
   int bp_tscale = 0, bp_xscale = 0;
   // residual buffers of the last sacopt_get_costs call (still in the arena), for sacopt_recost_last
+  struct CostBufs {
+    std::vector<const int32_t *> e;     // error[ch]     [frame][cand][channel]
+    std::vector<const int32_t *> u;     // s2u_error[ch] (same order)
+    std::vector<const int32_t *> umax;  // address of max s2u_error[ch] (same order)
+    std::vector<int> n;                 // window length per frame
+  };
   struct Kept {
     bool valid = false;
     int nframes = 0, ncand = 0;
-    std::vector<const int32_t *> bufs;  // [frame][cand][channel]
-    std::vector<int> n;                 // window length per frame
+    CostBufs b;
     size_t mark = 0;                    // arena position behind the kept data
   } kept;
+  int cost_fn = SACOPT_COST_GOLOMB;     // CostFunction the optimizer minimises (sacopt_set_cost_function)
   // sacopt_cost_golomb_noalloc: device address of this GPU's file-scope scratch array (kernels.hip), taken once at create
   unsigned char *na_scratch = nullptr;
   size_t na_stage_bytes = 0, na_ctl_doubles = 0;
@@ -370,6 +378,13 @@ extern "C" void sacopt_destroy(sacopt_ctx *c) {
   for (hipStream_t p : c->split) if (p) (void)hipStreamDestroy(p);
   if (c->st) (void)hipStreamDestroy(c->st);
   delete c;
+}
+
+extern "C" int sacopt_set_cost_function(sacopt_ctx *c, int which) {
+  if (!c) return 1;
+  if (which != SACOPT_COST_GOLOMB && which != SACOPT_COST_MEANRMS && which != SACOPT_COST_BITPLANE) { c->err = "unknown cost function"; return 1; }
+  c->cost_fn = which;
+  return 0;
 }
 
 extern "C" int sacopt_last_timing(const sacopt_ctx *c, double *total_ms, double *lms_ms, int *lms_launches,
@@ -1194,54 +1209,108 @@ extern "C" int sacopt_predict_stereo_frames(sacopt_ctx *c, int profile, int nfra
 }
 
 // ------------------------------------------------------------------------------------------ GetCost / Optimize
-// Cost of `ncand` candidates per frame, in order, CostGolomb state carried (d_state[f]).
-// bufs: residual buffers [frame][cand][channel] on the device; ns: window length per frame.
-static int cost_round_bufs(sacopt_ctx *c, int nframes, int ncand, const std::vector<const int32_t *> &bufs, const std::vector<int> &ns,
-                           double *d_state, std::vector<double> &costs_host) {
-  const int32_t **d_bufs;
-  if (upload(c, bufs, &d_bufs)) return 1;
-  double *d_costs = arena_alloc<double>(c, (size_t)nframes * ncand);
-  if (!d_costs) { c->err = "device arena exhausted"; return 1; }
-  std::vector<CostJob> jobs(nframes);
-  for (int f = 0; f < nframes; f++) {
-    jobs[f].bufs = d_bufs + 2 * (size_t)f * ncand;
-    jobs[f].costs = d_costs + (size_t)f * ncand;
-    jobs[f].state = d_state + f;
-    jobs[f].n = ns[f];
-    jobs[f].nbuf = 2 * ncand;
-    jobs[f].scr = arena_alloc<double>(c, 6 * (size_t)ncand);
-    jobs[f].ok = arena_alloc<int32_t>(c, 1);
-    if (!jobs[f].scr || !jobs[f].ok) { c->err = "device arena exhausted"; return 1; }
+// Cost of `ncand` candidates per frame, in call order: (Calc(error[0]) + Calc(error[1])) / 2 (GetCost, codec.cpp:349-351) with the
+// context's CostFunction. CostGolomb: running mean carried from call to call (d_state[f]); the other two carry nothing.
+static int ilog2(int v);
+static int cost_round_bufs(sacopt_ctx *c, int nframes, int ncand, const sacopt_ctx::CostBufs &cb, double *d_state, std::vector<double> &costs_host) {
+  const size_t nb = 2 * (size_t)nframes * ncand;
+  costs_host.assign((size_t)nframes * ncand, 0.);
+  if (c->cost_fn == SACOPT_COST_GOLOMB) {
+    const int32_t **d_bufs;
+    if (upload(c, cb.e, &d_bufs)) return 1;
+    double *d_costs = arena_alloc<double>(c, (size_t)nframes * ncand);
+    if (!d_costs) { c->err = "device arena exhausted"; return 1; }
+    std::vector<CostJob> jobs(nframes);
+    for (int f = 0; f < nframes; f++) {
+      jobs[f].bufs = d_bufs + 2 * (size_t)f * ncand;
+      jobs[f].costs = d_costs + (size_t)f * ncand;
+      jobs[f].state = d_state + f;
+      jobs[f].n = cb.n[f];
+      jobs[f].nbuf = 2 * ncand;
+      jobs[f].scr = arena_alloc<double>(c, 6 * (size_t)ncand);
+      jobs[f].ok = arena_alloc<int32_t>(c, 1);
+      if (!jobs[f].scr || !jobs[f].ok) { c->err = "device arena exhausted"; return 1; }
+    }
+    CostJob *dj;
+    if (upload(c, jobs, &dj)) return 1;
+    if (sacopt_launch_cost_par(dj, nframes, 2 * ncand, c->d_pow2, c->st)) { c->err = "k_cost launch failed"; return 1; }
+    HIPCK(c, hipMemcpyAsync(costs_host.data(), d_costs, costs_host.size() * 8, hipMemcpyDeviceToHost, c->st));
+    HIPCK(c, hipStreamSynchronize(c->st));
+    return 0;
   }
-  CostJob *dj;
-  if (upload(c, jobs, &dj)) return 1;
-  if (sacopt_launch_cost_par(dj, nframes, 2 * ncand, c->d_pow2, c->st)) { c->err = "k_cost launch failed"; return 1; }
-  costs_host.resize((size_t)nframes * ncand);
-  HIPCK(c, hipMemcpyAsync(costs_host.data(), d_costs, costs_host.size() * 8, hipMemcpyDeviceToHost, c->st));
-  HIPCK(c, hipStreamSynchronize(c->st));
+  std::vector<int32_t> ns(nb);
+  for (size_t i = 0; i < nb; i++) ns[i] = cb.n[i / (2 * (size_t)ncand)];
+  std::vector<double> per(nb, 0.);
+  if (c->cost_fn == SACOPT_COST_MEANRMS) {  // CostMeanRMS::Calc, codec.cpp:302-312
+    const int32_t **d_bufs;
+    int32_t *d_ns;
+    if (upload(c, cb.e, &d_bufs) || upload(c, ns, &d_ns)) return 1;
+    double *d_out = arena_alloc<double>(c, nb);
+    if (!d_out) { c->err = "device arena exhausted"; return 1; }
+    if (sacopt_launch_meanrms_batch(d_bufs, d_ns, (int)nb, d_out, c->st)) { c->err = "k_meanrms launch failed"; return 1; }
+    HIPCK(c, hipMemcpyAsync(per.data(), d_out, nb * 8, hipMemcpyDeviceToHost, c->st));
+    HIPCK(c, hipStreamSynchronize(c->st));
+  } else {  // bits per sample the host's bit-plane coder spends on the buffer (a fresh coder per buffer, as Encode() has)
+    const int32_t **d_um;
+    if (upload(c, cb.umax, &d_um)) return 1;
+    int32_t *d_mx = arena_alloc<int32_t>(c, nb);
+    if (!d_mx) { c->err = "device arena exhausted"; return 1; }
+    if (sacopt_launch_gather_i32(d_um, (int)nb, d_mx, c->st)) { c->err = "gather launch failed"; return 1; }
+    std::vector<int32_t> mx(nb);
+    HIPCK(c, hipMemcpyAsync(mx.data(), d_mx, nb * 4, hipMemcpyDeviceToHost, c->st));
+    HIPCK(c, hipStreamSynchronize(c->st));
+    std::vector<BpJob> jobs(nb);
+    int maxn = 0, maxplanes = 1;
+    for (size_t i = 0; i < nb; i++) {
+      jobs[i].buf = cb.u[i]; jobs[i].n = ns[i]; jobs[i].maxbpn = ilog2(mx[i]);  // framestats[ch].maxbpn, codec.cpp:207-208
+      maxn = ns[i] > maxn ? ns[i] : maxn;
+      maxplanes = jobs[i].maxbpn + 1 > maxplanes ? jobs[i].maxbpn + 1 : maxplanes;
+    }
+    const size_t nblk = (nb + 63) / 64, nctx = (size_t)maxplanes * 32;
+    BpJob *dj;
+    if (upload(c, jobs, &dj)) return 1;
+    int32_t *T = arena_alloc<int32_t>(c, nblk * (size_t)(maxn ? maxn : 1) * 64);
+    uint8_t *msb = arena_alloc<uint8_t>(c, nblk * ((size_t)maxn + 16) * 64);
+    uint32_t *sse = arena_alloc<uint32_t>(c, nblk * nctx * 66 * 64);
+    uint8_t *lb = arena_alloc<uint8_t>(c, nblk * nctx * 64);
+    int32_t *dsz = arena_alloc<int32_t>(c, nb);
+    if (!T || !msb || !sse || !lb || !dsz) { c->err = "device arena exhausted (bit-plane cost)"; return 1; }
+    if (sacopt_launch_bpsize(dj, (int)nb, maxn, maxplanes, T, msb, sse, lb, c->d_bp_fwd, c->d_bp_inv, c->d_bp_sse, c->bp_tscale, c->bp_xscale, dsz, c->st)) { c->err = "k_bpsize launch failed"; return 1; }
+    std::vector<int32_t> sz(nb);
+    HIPCK(c, hipMemcpyAsync(sz.data(), dsz, nb * 4, hipMemcpyDeviceToHost, c->st));
+    HIPCK(c, hipStreamSynchronize(c->st));
+    for (size_t i = 0; i < nb; i++) per[i] = ns[i] ? 8. * (double)sz[i] / (double)ns[i] : 0.;
+  }
+  for (size_t k = 0; k < costs_host.size(); k++) costs_host[k] = (per[2 * k] + per[2 * k + 1]) / 2.;
   return 0;
 }
-static void chain_bufs(const ProfDesc &pd, const std::vector<DevFrame> &fr, const std::vector<Chain> &chains, int ncand,
-                       std::vector<const int32_t *> &bufs, std::vector<int> &ns) {
+// arena bytes the bit-plane cost of one round needs beyond the chains themselves (nb buffers of up to n samples, 32 planes at most)
+static size_t bitplane_cost_bytes(size_t nb, int n, int planes) {
+  const size_t nblk = (nb + 63) / 64;
+  return nblk * ((size_t)n * 256 + ((size_t)n + 16) * 64 + (size_t)planes * 32 * (66 * 256 + 64)) + nb * 64 + 65536;
+}
+static void chain_bufs(const ProfDesc &pd, const std::vector<DevFrame> &fr, const std::vector<Chain> &chains, int ncand, sacopt_ctx::CostBufs &cb) {
   const int nframes = (int)fr.size();
   const int last = (pd.type == SACOPT_PROFILE_FAST) ? 0 : pd.nlms + 1;
-  bufs.resize(2 * (size_t)nframes * ncand);
-  ns.resize(nframes);
+  const size_t nb = 2 * (size_t)nframes * ncand;
+  cb.e.resize(nb); cb.u.resize(nb); cb.umax.resize(nb);
+  cb.n.resize(nframes);
   for (int f = 0; f < nframes; f++) {
-    ns[f] = fr[f].n;
+    cb.n[f] = fr[f].n;
     for (int k = 0; k < ncand; k++) {
       const Chain &ch = chains[(size_t)f * ncand + k];
-      bufs[2 * ((size_t)f * ncand + k)] = ch.sb[last].e[0];
-      bufs[2 * ((size_t)f * ncand + k) + 1] = ch.sb[last].e[1];
+      for (int h = 0; h < 2; h++) {
+        const size_t i = 2 * ((size_t)f * ncand + k) + h;
+        cb.e[i] = ch.sb[last].e[h]; cb.u[i] = ch.sb[last].u[h]; cb.umax[i] = ch.sb[last].umax + h;
+      }
     }
   }
 }
 static int cost_round(sacopt_ctx *c, const ProfDesc &pd, const std::vector<DevFrame> &fr, const std::vector<Chain> &chains,
                       int ncand, double *d_state, std::vector<double> &costs_host) {
-  std::vector<const int32_t *> bufs;
-  std::vector<int> ns;
-  chain_bufs(pd, fr, chains, ncand, bufs, ns);
-  return cost_round_bufs(c, (int)fr.size(), ncand, bufs, ns, d_state, costs_host);
+  sacopt_ctx::CostBufs cb;
+  chain_bufs(pd, fr, chains, ncand, cb);
+  return cost_round_bufs(c, (int)fr.size(), ncand, cb, d_state, costs_host);
 }
 
 extern "C" int sacopt_get_costs(sacopt_ctx *c, int profile, int nframes, const sacopt_frame *frames, const int32_t *from,
@@ -1259,6 +1328,11 @@ extern "C" int sacopt_get_costs(sacopt_ctx *c, int profile, int nframes, const s
     need += (size_t)ncand * chain_bytes(pd, nn > 0 ? nn : 0) + 2 * (((size_t)frames[f].numsamples * 4 + 255) & ~(size_t)255) + 4096 +
             (size_t)ncand * (64 + lpc_scratch_bytes(pd, nn > 0 ? nn : 0) + sizeof(LpcJob) + 256) +
             2 * ((size_t)ncand * (16 + 8 + 48) + sizeof(CostJob) + 2048);  // cost tables, twice: one more set for sacopt_recost_last
+  }
+  if (c->cost_fn == SACOPT_COST_BITPLANE) {
+    int mxn = 0;
+    for (int f = 0; f < nframes; f++) { const int nn = n ? n[f] : frames[f].numsamples - (from ? from[f] : 0); mxn = nn > mxn ? nn : mxn; }
+    need += 2 * bitplane_cost_bytes(2 * (size_t)nframes * ncand, mxn, 32);
   }
   if (arena_reserve(c, need)) return 1;
   HIPCK(c, hipEventRecord(c->ev0, c->st));
@@ -1283,7 +1357,7 @@ extern "C" int sacopt_get_costs(sacopt_ctx *c, int profile, int nframes, const s
   if (cost_state) HIPCK(c, hipMemcpyAsync(cost_state, d_state, (size_t)nframes * 8, hipMemcpyDeviceToHost, c->st));
   if (end_timing(c)) return 1;
   // the residuals stay where they are until the next call: sacopt_recost_last can cost them again from another state
-  chain_bufs(pd, fr, chains, ncand, c->kept.bufs, c->kept.n);
+  chain_bufs(pd, fr, chains, ncand, c->kept.b);
   c->kept.nframes = nframes; c->kept.ncand = ncand; c->kept.mark = c->used; c->kept.valid = true;
   return 0;
 }
@@ -1305,7 +1379,7 @@ extern "C" int sacopt_recost_last(sacopt_ctx *c, double *costs, double *cost_sta
   double *d_state;
   if (upload(c, st, &d_state)) return 1;
   std::vector<double> ch_costs;
-  if (cost_round_bufs(c, nframes, c->kept.ncand, c->kept.bufs, c->kept.n, d_state, ch_costs)) return 1;
+  if (cost_round_bufs(c, nframes, c->kept.ncand, c->kept.b, d_state, ch_costs)) return 1;
   memcpy(costs, ch_costs.data(), ch_costs.size() * 8);
   if (cost_state) {
     HIPCK(c, hipMemcpyAsync(cost_state, d_state, (size_t)nframes * 8, hipMemcpyDeviceToHost, c->st));
@@ -1425,6 +1499,11 @@ extern "C" int sacopt_optimize_frames(sacopt_ctx *c, int profile, int nframes, c
     from[f] = (frames[f].numsamples - wn[f]) / 2;
     need += optimize_bytes(pd, ncoef_loop, grid, total_cand, wn[f]) + 2 * (((size_t)frames[f].numsamples * 4 + 255) & ~(size_t)255);
   }
+  if (c->cost_fn == SACOPT_COST_BITPLANE) {  // scratch of the bit-plane cost, once per round (the arena only grows within a call)
+    int mxn = 0;
+    for (int f = 0; f < nframes; f++) mxn = wn[f] > mxn ? wn[f] : mxn;
+    need += (size_t)(ncoef_loop + 1) * bitplane_cost_bytes(2 * (size_t)nframes * 66, mxn, 32);
+  }
   if (arena_reserve(c, need)) return 1;
   HIPCK(c, hipEventRecord(c->ev0, c->st));
   std::vector<DevFrame> fr;
@@ -1461,6 +1540,11 @@ extern "C" int sacopt_encode_frames(sacopt_ctx *c, int profile, int nframes, con
     need += chain_bytes(pd, ns) + 2 * (((size_t)ns * 4 + 255) & ~(size_t)255) + 4096 + lpc_scratch_bytes(pd, ns) + sizeof(LpcJob) + 256 + pipe_bytes(ns) +
             ((out[f].map0 || out[f].map1) ? map_bytes(ns) : 0);
     if (ncoef_loop > 0) need += optimize_bytes(pd, ncoef_loop, grid, total_cand, ns / 8);
+  }
+  if (ncoef_loop > 0 && c->cost_fn == SACOPT_COST_BITPLANE) {
+    int mxn = 0;
+    for (int f = 0; f < nframes; f++) mxn = frames[f].numsamples / 8 > mxn ? frames[f].numsamples / 8 : mxn;
+    need += (size_t)(ncoef_loop + 1) * bitplane_cost_bytes(2 * (size_t)nframes * 66, mxn, 32);
   }
   if (arena_reserve(c, need)) return 1;
   // small batches: the stream set that keeps the full-frame followers off the optimizer's CUs (see sacopt_create)

@@ -15,6 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SACOPT_LIB") or os.path.join(_HERE, "libsacopt.so")  # SACOPT_LIB: instrumented builds of tools/ only
 
 PROFILE_FAST, PROFILE_NORMAL, PROFILE_HIGH, PROFILE_HIGH32 = 0, 1, 2, 3
+COST_GOLOMB, COST_MEANRMS, COST_BITPLANE = 0, 1, 2
 NCOEF = {0: 1, 1: 6, 2: 8, 3: 8}
 
 
@@ -52,6 +53,7 @@ def lib():
                                                    C.c_void_p, C.c_void_p]
         L.sacopt_get_costs.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                        C.c_void_p, C.c_void_p, C.c_void_p]
+        L.sacopt_set_cost_function.argtypes = [C.c_void_p, C.c_int]
         L.sacopt_recost_last.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.sacopt_optimize_frames.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                              C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
@@ -74,7 +76,7 @@ def lib():
 
 
 EXPORTS = ["sacopt_create", "sacopt_destroy", "sacopt_last_error", "sacopt_probe_rsqrt", "sacopt_base_profile",
-           "sacopt_predict_stereo_frames", "sacopt_get_costs", "sacopt_recost_last", "sacopt_optimize_frames", "sacopt_encode_frames", "sacopt_unpredict_stereo_frames", "sacopt_cost_golomb", "sacopt_cost_golomb_noalloc", "sacopt_coded_sizes",
+           "sacopt_predict_stereo_frames", "sacopt_set_cost_function", "sacopt_get_costs", "sacopt_recost_last", "sacopt_optimize_frames", "sacopt_encode_frames", "sacopt_unpredict_stereo_frames", "sacopt_cost_golomb", "sacopt_cost_golomb_noalloc", "sacopt_coded_sizes",
            "sacopt_cost_meanrms", "sacopt_lms_pair", "sacopt_lpc3_pair", "sacopt_rls_run", "sacopt_chol_solve", "sacopt_serial_sum",
            "sacopt_cascade_trace", "sacopt_last_timing"]
 
@@ -223,6 +225,10 @@ class Context:
         st = np.zeros(nf) if state is None else np.ascontiguousarray(state, dtype=np.float64).copy()
         self._ck(lib().sacopt_get_costs(self._h, profile, nf, arr, _p(frm_a), _p(n_a), ncand, _p(cc), _p(costs), _p(st)))
         return costs, st
+
+    def set_cost_function(self, which):
+        """0 CostGolomb (the reference's choice), 1 CostMeanRMS, 2 bit-plane coder size."""
+        self._ck(lib().sacopt_set_cost_function(self._h, which))
 
     def recost_last(self, nframes, ncand, state=None):
         """sacopt_recost_last: the candidates of the last get_costs call from another start state."""

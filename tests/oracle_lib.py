@@ -213,12 +213,13 @@ class Oracle(_Lib):
             return (o1[:n1].tobytes() if want_bytes else n1), False, int(maxbpn)
         return (o2[:n2].tobytes() if want_bytes else n2), True, int(maxbpn_map)
 
-    def optimize(self, profile, s0, s1, prof=None, ncoef_loop=8, max_rows=128):
+    def optimize(self, profile, s0, s1, prof=None, ncoef_loop=8, max_rows=128, cost_fn=0):
+        """cost_fn: 0 CostGolomb, 1 CostMeanRMS, 2 bit-plane coder size."""
         s0 = np.ascontiguousarray(s0, dtype=np.int32); s1 = np.ascontiguousarray(s1, dtype=np.int32)
         best = np.zeros(8); trace = np.zeros((max_rows, 3))
         pf = None if prof is None else np.ascontiguousarray(prof, dtype=np.float64)
-        rows = self.lib.oracle_optimize(C.c_int(profile), _ptr(pf), C.c_int(ncoef_loop), _ptr(s0), _ptr(s1),
-                                        C.c_int(len(s0)), _ptr(best), _ptr(trace), C.c_int(max_rows))
+        rows = self.lib.oracle_optimize_cf(C.c_int(profile), _ptr(pf), C.c_int(ncoef_loop), _ptr(s0), _ptr(s1),
+                                           C.c_int(len(s0)), C.c_int(cost_fn), _ptr(best), _ptr(trace), C.c_int(max_rows))
         return best, trace[:rows].copy()
 
 
@@ -235,10 +236,10 @@ class Ref(_Lib):
         n = self.lib.ref_optimize(C.c_int(profile), _ptr(s0), _ptr(s1), C.c_int(len(s0)), _ptr(best))
         return best[:max(n, 0)], n
 
-    def optimize_trace(self, profile, s0, s1, ncoef_loop=8, max_rows=128):
+    def optimize_trace(self, profile, s0, s1, ncoef_loop=8, max_rows=128, meanrms=False):
         s0 = np.ascontiguousarray(s0, dtype=np.int32); s1 = np.ascontiguousarray(s1, dtype=np.int32)
         best = np.zeros(8); trace = np.zeros((max_rows, 3))
-        rows = self.lib.ref_optimize_trace(C.c_int(profile), _ptr(s0), _ptr(s1), C.c_int(len(s0)),
+        rows = (self.lib.ref_optimize_trace_meanrms if meanrms else self.lib.ref_optimize_trace)(C.c_int(profile), _ptr(s0), _ptr(s1), C.c_int(len(s0)),
                                            C.c_int(ncoef_loop), _ptr(best), _ptr(trace), C.c_int(max_rows))
         return best, trace[:rows].copy()
 

@@ -188,3 +188,24 @@ def test_coded_sizes_vs_restated_coder(oracle):
         b = np.ascontiguousarray(b, dtype=np.int32)
         want = oracle.lib.oracle_encode_mono_normal(b.ctypes.data_as(C.c_void_p), C.c_int(len(b)), C.c_int(int(m)), None, C.c_int(0))
         assert got[i] == want, (i, len(b), m, got[i], want)
+
+
+@pytest.mark.parametrize("cost_fn,prof,lens", [(1, 2, [4096, 3000]), (1, 1, [5000]), (2, 2, [4096, 3000]), (2, 0, [2500])])
+def test_optimize_other_cost_functions_vs_oracle(rsqrt_table, oracle, cost_fn, prof, lens):
+    # CostFunction is an interface in the reference (codec.h:10-15): Optimize with CostMeanRMS (codec.cpp:302-312; oracle
+    # pinned against the reference's class: test_oracle_vs_ref.py::test_optimize_with_cost_mean_rms) and with the bit-plane
+    # coder's size (no reference counterpart: oracle rows) -- winners and every (coef, x, cost) row bit-equal
+    frames = [stereo_clip(110 + i, n) for i, n in enumerate(lens)]
+    with sacopt.Context(0, *rsqrt_table) as c:
+        c.set_cost_function(cost_fn)
+        best, traces, rows = c.optimize(prof, frames, ncoef_loop=sacopt.NCOEF[prof])
+        base = sacopt.base_profile(prof)[:, 2]
+        costs, _ = c.get_costs(prof, frames, np.tile(base, (len(frames), 1, 1)), frm=[(n - n // 8) // 2 for n in lens], n=[n // 8 for n in lens])
+        c.set_cost_function(sacopt.COST_GOLOMB)
+        best_g, _, _ = c.optimize(prof, frames[:1], ncoef_loop=sacopt.NCOEF[prof])
+    for f, (L, R) in enumerate(frames):
+        ob, ot = oracle.optimize(prof, L, R, ncoef_loop=sacopt.NCOEF[prof], cost_fn=cost_fn)
+        assert same_bits(best[f], ob[:sacopt.NCOEF[prof]]) and same_bits(traces[f], ot), f
+        assert same_bits(costs[f], ot[0, 2:3])   # GetCost of the base profile = the baseline row
+    og, _ = oracle.optimize(prof, *frames[0], ncoef_loop=sacopt.NCOEF[prof])
+    assert same_bits(best_g[0], og[:sacopt.NCOEF[prof]])   # back on CostGolomb the context is the reference again

@@ -209,3 +209,12 @@ def test_bitplane_coder_bytes(pair):
             assert got == want[ch], (prof, ch, len(got[0]), len(want[ch][0]), got[1:], want[ch][1:])
             mapped_seen |= got[1]; plain_seen |= not got[1]
     assert mapped_seen and plain_seen
+
+
+def test_optimize_with_cost_mean_rms(pair):
+    # FrameCoder::Optimize's schedule driven with the reference's OTHER CostFunction, CostMeanRMS (codec.cpp:302-312)
+    o, r = pair
+    L, R = stereo_clip(45, 4096)
+    bo, to = o.optimize(2, L, R, cost_fn=1)
+    br, tr = r.optimize_trace(2, L, R, meanrms=True)
+    assert to.tobytes() == tr.tobytes() and bo.tobytes() == br.tobytes()

@@ -17,17 +17,25 @@ orc = oracle_lib.Oracle()
 L, R = stereo_clip(1000, nfr * FRAME)
 frames = [(L[f * FRAME:(f + 1) * FRAME], R[f * FRAME:(f + 1) * FRAME]) for f in range(nfr)]
 rows = []
+import time
 with sacopt.Context(0) as ctx:
-    best, traces, _ = ctx.optimize(prof, frames)
+    t0 = time.perf_counter(); best, traces, _ = ctx.optimize(prof, frames); t_g = time.perf_counter() - t0
+    ctx.set_cost_function(sacopt.COST_BITPLANE)
+    t0 = time.perf_counter(); best_b, traces_b, _ = ctx.optimize(prof, frames); t_b = time.perf_counter() - t0
+    ctx.set_cost_function(sacopt.COST_GOLOMB)
     base = ctx.predict(prof, frames, maps=True)
     opt = ctx.predict(prof, frames, coefs=best, maps=True)
+    opt_b = ctx.predict(prof, frames, coefs=best_b, maps=True)
+    print(json.dumps(dict(optimize_s_cost_golomb=t_g, optimize_s_cost_bitplane=t_b)), flush=True)
     for f, (l, r) in enumerate(frames):
         size = lambda o: sum(orc.encode_channel(o[f"u{c}"], o["maxbpn"][c], o[f"m{c}"], o["maxbpn"][2 + c], orc.remap_tables(x), want_bytes=False)[0]
                              for c, x in enumerate((l, r)))
-        b, o = size(base[f]), size(opt[f])
+        b, o, ob = size(base[f]), size(opt[f]), size(opt_b[f])
         tr = traces[f]
-        rows.append(dict(frame=f, base_bytes=b, opt_bytes=o, saving_pct=100. * (b - o) / b, golomb_base=float(tr[0, 2]), golomb_best=float(tr[:, 2].min()),
+        rows.append(dict(frame=f, base_bytes=b, opt_bytes=o, saving_pct=100. * (b - o) / b, opt_bytes_bitplane_objective=ob,
+                         saving_pct_bitplane_objective=100. * (b - ob) / b, window_bits_base=float(traces_b[f][0, 2]), window_bits_best=float(traces_b[f][:, 2].min()), golomb_base=float(tr[0, 2]), golomb_best=float(tr[:, 2].min()),
                          best=[float(x) for x in best[f]]))
         print(json.dumps(rows[-1]), flush=True)
-tb, to = sum(r["base_bytes"] for r in rows), sum(r["opt_bytes"] for r in rows)
-print(json.dumps(dict(profile=prof, frames=nfr, base_bytes=tb, opt_bytes=to, saving_pct=100. * (tb - to) / tb, pcm_bytes=nfr * FRAME * 4)))
+tb, to, tob = sum(r["base_bytes"] for r in rows), sum(r["opt_bytes"] for r in rows), sum(r["opt_bytes_bitplane_objective"] for r in rows)
+print(json.dumps(dict(profile=prof, frames=nfr, base_bytes=tb, opt_bytes_cost_golomb=to, saving_pct_cost_golomb=100. * (tb - to) / tb,
+                      opt_bytes_cost_bitplane=tob, saving_pct_cost_bitplane=100. * (tb - tob) / tb, pcm_bytes=nfr * FRAME * 4)))
