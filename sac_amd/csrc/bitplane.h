@@ -61,6 +61,8 @@ __global__ __launch_bounds__(64) void k_bpsize(const BpJob *__restrict__ jobs, i
   __shared__ uint16_t divt[BP_DIVN];
   __shared__ uint16_t c1[BP_NC1][64], c2[BP_NC2][64];
   __shared__ int wts[BP_NW][64];
+  __shared__ uint32_t lbm[32][64];  // SSENL::lb of context (bpn << 5) + msb: bit msb of word [bpn][lane] (a global byte per context was a
+                                    // dependent L2 round trip in front of the map entries' addresses)
   const int lane = threadIdx.x, blk = blockIdx.x, b = blk * 64 + lane;
   for (int i = lane; i < BP_PSCALE; i += 64) fwd[i] = tb.fwd[i];
   for (int i = lane; i < (1 << BP_DBITS); i += 64) inv[i] = tb.inv[i];
@@ -68,16 +70,16 @@ __global__ __launch_bounds__(64) void k_bpsize(const BpJob *__restrict__ jobs, i
   for (int i = 0; i < BP_NC1; i++) c1[i][lane] = BP_PSCALE >> 1;
   for (int i = 0; i < BP_NC2; i++) c2[i][lane] = BP_PSCALE >> 1;
   for (int i = 0; i < BP_NW; i++) wts[i][lane] = 0;  // NMixLogistic::Init(0)
+  for (int i = 0; i < 32; i++) lbm[i][lane] = 0;
   const bool live = b < nbuf;
   const int n = live ? jobs[b].n : 0, mbp = live ? jobs[b].maxbpn : -1;
   const int32_t *Tb = T + (size_t)blk * maxn * 64 + lane;
   uint8_t *msb = msb_g + (size_t)blk * (maxn + 16) * 64 + lane;       // [s + 4][lane]: zero entries on either side
   const int nctx = maxplanes * 32;
   uint32_t *sse = sse_g + (size_t)blk * nctx * 66 * 64 + lane;         // [(ctx * 2 + lb) * 33 + q][lane]: p1 | counter << 16
-  uint8_t *lbp = lb_g + (size_t)blk * nctx * 64 + lane;
+  (void)lb_g;
   for (int s = 0; s < maxn + 16; s++) msb[(size_t)s * 64] = 0;
   for (int e = 0; e < nctx * 66; e++) sse[(size_t)e * 64] = tb.sse_init[e % 33];  // SSENL ctor, sse.h:94-105
-  for (int e = 0; e < nctx; e++) lbp[(size_t)e * 64] = 0;
   __syncthreads();
   const int tscale = tb.tscale, xscale = tb.xscale;
 
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(64) void k_bpsize(const BpJob *__restrict__ jobs, i
         const int pd = bp_clamp(dinv((int)bp_idiv64(sum, BP_WBITS)), 1, BP_PSCALEm);
         // SSENL::Predict, sse.h:106-118  (context (bpn << 5) + msb, vle.cpp:98)
         const int ctx = (bpn << 5) + mymsb;
-        const int lb = lbp[(size_t)ctx * 64];
+        const int lb = (int)((lbm[bpn][lane] >> mymsb) & 1u);
         int pq = (int)fwd[pd] + tscale;
         pq = pq < 0 ? 0 : (pq > 2 * tscale ? 2 * tscale : pq);
         const int q = pq / xscale, pmod = pq - q * xscale;
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(64) void k_bpsize(const BpJob *__restrict__ jobs, i
         // UpdateSSE (vle.cpp:104-108): both bins at limit 1000, lb = bit; final mixer at 300
         lcl(e0, bit, 1000);
         lcl(e1, bit, 1000);
-        lbp[(size_t)ctx * 64] = (uint8_t)bit;
+        lbm[bpn][lane] = (lbm[bpn][lane] & ~(1u << mymsb)) | ((uint32_t)bit << mymsb);
         {
           const int err = (bit << BP_PBITS) - pf;
           wf[0] = bp_clamp(wf[0] + bp_idiv32(bp_idiv32(y0 * err, BP_DBITS) * 300, BP_DBITS), -BP_WRANGE, BP_WRANGE - 1);
