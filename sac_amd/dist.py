@@ -26,7 +26,7 @@ def gather_frame_rows(local_rows: np.ndarray, nframes: int, world: int, rank: in
     import torch.distributed as dist
     local_rows = np.ascontiguousarray(local_rows, dtype=np.float64)
     ncol = local_rows.shape[1] if local_rows.ndim == 2 else 0
-    if world == 1:
+    if world == 1 and not (dist.is_available() and dist.is_initialized()):
         return local_rows.reshape(nframes, ncol)
     per = (nframes + world - 1) // world
     pad = np.zeros((per, ncol), np.float64)

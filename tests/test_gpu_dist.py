@@ -62,3 +62,35 @@ def test_candidate_split_ranks_one_gpu(rsqrt_table, world, profile, lens, bits):
         for k in range(len(lens)):
             assert t[k].tobytes() == np.ascontiguousarray(traces[k]).tobytes(), (rank, k)
             assert b[k].tobytes() == np.ascontiguousarray(best[k]).tobytes(), (rank, k)
+
+
+def _rccl_worker(port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    from sac_amd.dist import gather_frame_rows
+    rows = np.arange(15 * 12, dtype=np.float64).reshape(15, 12) * 0.25
+    full = gather_frame_rows(rows, 15, 1, 0)          # the nccl branch: device tensors through RCCL's all_gather
+    t = torch.tensor([3.5], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)          # bench.py's max-over-ranks
+    dist.broadcast(t, src=0)                          # optimize_split's chained path
+    q.put((full.tobytes() == rows.tobytes(), float(t.item()), dist.get_backend()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_result_gather_over_rccl_single_rank():
+    # the box has one GPU, so RCCL can only be run with a world of one rank: what this pins is that the `nccl` branches of
+    # sac_amd.dist (device tensors, all_gather / broadcast) and of bench.py execute at all on this stack
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mctx = mp.get_context("spawn")
+    q = mctx.Queue()
+    p = mctx.Process(target=_rccl_worker, args=(port, q))
+    p.start()
+    ok, v, backend = q.get(timeout=240)
+    p.join(timeout=60)
+    assert p.exitcode == 0 and ok and v == 3.5 and backend == "nccl"
