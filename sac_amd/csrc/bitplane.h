@@ -10,6 +10,7 @@
 // (log / exp of the host libm), is tabulated by the host at sacopt_create and read from LDS.
 //   LDS (per wave):  stretch table 32768 x int16, squash table 4096 x uint16, 1/(n+3) table, and per lane the 322 bit
 //                    counters and 42 mixer weights ([element][lane]: bank = lane, conflict-free whatever the contexts are)
+//                    and the SSE stage's last-bit flags (a bit per context)
 //   HBM (per wave):  residuals transposed to [sample][lane] (coalesced), msb[sample][lane], and the SSE maps
 //                    [context][2][33][lane] -- (maxbpn+1) x 32 contexts of 264 bytes per lane do not fit the LDS.
 #define BP_PBITS 15
