@@ -209,3 +209,41 @@ def test_optimize_other_cost_functions_vs_oracle(rsqrt_table, oracle, cost_fn, p
         assert same_bits(costs[f], ot[0, 2:3])   # GetCost of the base profile = the baseline row
     og, _ = oracle.optimize(prof, *frames[0], ncoef_loop=sacopt.NCOEF[prof])
     assert same_bits(best_g[0], og[:sacopt.NCOEF[prof]])   # back on CostGolomb the context is the reference again
+
+
+def test_round2_entry_points_error_paths(rsqrt_table):
+    # non-zero status + message, nothing thrown across the ABI, context usable afterwards
+    import ctypes as C
+    L = sacopt.lib()
+    with sacopt.Context(0, *rsqrt_table) as c:
+        h = c._h
+        assert L.sacopt_set_cost_function(h, 7) != 0 and b"unknown cost function" in L.sacopt_last_error(h)
+        costs = np.zeros(4); st = np.zeros(1)
+        assert L.sacopt_recost_last(h, costs.ctypes.data_as(C.c_void_p), st.ctypes.data_as(C.c_void_p)) != 0
+        assert b"no sacopt_get_costs call" in L.sacopt_last_error(h)
+        x = np.zeros(100); out = np.zeros(1)
+        assert L.sacopt_serial_sum(h, 100, x.ctypes.data_as(C.c_void_p), 1, out.ctypes.data_as(C.c_void_p)) != 0
+        snap = np.zeros(400); sol = np.zeros(400); fail = C.c_int(0)
+        assert L.sacopt_chol_solve(h, 16, 0, snap.ctypes.data_as(C.c_void_p), sol.ctypes.data_as(C.c_void_p), C.byref(fail)) != 0
+        assert L.sacopt_chol_solve(h, 32, 1, snap.ctypes.data_as(C.c_void_p), sol.ctypes.data_as(C.c_void_p), C.byref(fail)) != 0   # LPC2's form exists for 24 taps only
+        with pytest.raises(sacopt.SacoptError, match="maxbpn"):
+            c.coded_sizes([np.zeros(10, np.int32)], [31])
+        with pytest.raises(sacopt.SacoptError):
+            c.cascade_trace(0, np.zeros(64, np.int32), np.zeros(64, np.int32))   # the fast profile has no stages
+        with pytest.raises(sacopt.SacoptError, match="window outside frame"):
+            c.predict(2, [(np.zeros(100, np.int32), np.zeros(100, np.int32))], frm=[2 ** 31 - 10], n=[50])   # from + n overflows int32
+        arr = (sacopt.Frame * 1)(); arr[0].numsamples = -5
+        res = (sacopt.Residuals * 1)()
+        assert L.sacopt_predict_stereo_frames(h, 2, 1, arr, None, None, None, res) != 0 and b"negative numsamples" in L.sacopt_last_error(h)
+        assert L.sacopt_lpc3_pair(h, C.c_double(0.997), 20, 8, None, None, 0, None, None) != 0
+        # recost after a get_costs works, and any other call in between invalidates it
+        Lc, Rc = stereo_clip(120, 3000)
+        base = sacopt.base_profile(2)[:, 2]
+        c1, s1 = c.get_costs(2, [(Lc, Rc)], np.tile(base, (1, 2, 1)), frm=[300], n=[2000], state=[0.0])
+        c2, s2 = c.recost_last(1, 2, state=[0.0])
+        assert same_bits(c1, c2) and same_bits(s1, s2)
+        c3, _ = c.recost_last(1, 2, state=[5.0])
+        assert not same_bits(c1, c3)
+        c.cost_meanrms(np.arange(10, dtype=np.int32))
+        with pytest.raises(sacopt.SacoptError, match="no sacopt_get_costs call"):
+            c.recost_last(1, 2)
