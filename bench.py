@@ -263,7 +263,8 @@ def main():
                                  "latency of the serial 1920-term sums, the matrix pipe is used as an exact f64 adder, not a GEMM",
                          "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_VECTOR_PEAK_TFLOPS, "traffic": pmc_traffic() if nfr <= 20 else None,
-                         "workgroups_per_launch": wgs, "frac_of_occupied_cus": achieved / (FP64_VECTOR_PEAK_TFLOPS * min(wgs, 256) / 256.0),
+                         "workgroups_per_launch": wgs if nfr <= 20 else None,
+                         "frac_of_occupied_cus": achieved / (FP64_VECTOR_PEAK_TFLOPS * min(wgs, 256) / 256.0) if nfr <= 20 else None,
                          "avg_launch_ms": 1e3 * avg_launch_s, "launches": lms_launches,
                          "units_per_launch": units_per_launch, "flops_per_unit": FLOPS_LMS1},
         }

@@ -1502,7 +1502,7 @@ extern "C" int sacopt_optimize_frames(sacopt_ctx *c, int profile, int nframes, c
   if (c->cost_fn == SACOPT_COST_BITPLANE) {  // scratch of the bit-plane cost, once per round (the arena only grows within a call)
     int mxn = 0;
     for (int f = 0; f < nframes; f++) mxn = wn[f] > mxn ? wn[f] : mxn;
-    need += (size_t)(ncoef_loop + 1) * bitplane_cost_bytes(2 * (size_t)nframes * 66, mxn, 32);
+    need += (size_t)(ncoef_loop + 1) * bitplane_cost_bytes(2 * (size_t)nframes * 13, mxn, 32)  /* <= 12 candidates + the baseline per round */;
   }
   if (arena_reserve(c, need)) return 1;
   HIPCK(c, hipEventRecord(c->ev0, c->st));
@@ -1544,7 +1544,7 @@ extern "C" int sacopt_encode_frames(sacopt_ctx *c, int profile, int nframes, con
   if (ncoef_loop > 0 && c->cost_fn == SACOPT_COST_BITPLANE) {
     int mxn = 0;
     for (int f = 0; f < nframes; f++) mxn = frames[f].numsamples / 8 > mxn ? frames[f].numsamples / 8 : mxn;
-    need += (size_t)(ncoef_loop + 1) * bitplane_cost_bytes(2 * (size_t)nframes * 66, mxn, 32);
+    need += (size_t)(ncoef_loop + 1) * bitplane_cost_bytes(2 * (size_t)nframes * 13, mxn, 32)  /* <= 12 candidates + the baseline per round */;
   }
   if (arena_reserve(c, need)) return 1;
   // small batches: the stream set that keeps the full-frame followers off the optimizer's CUs (see sacopt_create)
