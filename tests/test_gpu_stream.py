@@ -247,3 +247,37 @@ def test_round2_entry_points_error_paths(rsqrt_table):
         c.cost_meanrms(np.arange(10, dtype=np.int32))
         with pytest.raises(sacopt.SacoptError, match="no sacopt_get_costs call"):
             c.recost_last(1, 2)
+
+
+# ---------------------------------------------------------------- the reference's own program with the GPU predictor linked in
+@pytest.mark.parametrize("prof,flag", [(0, "--fast"), (1, "--normal"), (2, "--high")])
+def test_reference_program_with_gpu_predictor(tmp_path, prof, flag):
+    # oracle/_ref/sac_gpu = the reference's main(), WAV reader, .sac writer and bit-plane coder, unmodified, with
+    # FrameCoder::Predict / Unpredict served by libsacopt through the C ABI (oracle/sac_gpu_shim.cpp; INTEGRATION.md as a
+    # program). It must write the file the reference's own binary writes -- also with the optimizer enabled ("ref+opt") --
+    # and decode a .sac file to the WAV the reference decodes it to (bit-exact input for fast / normal; for --high the
+    # reference's decoder clamps to [0, 0] and does not round-trip: the GPU decoder has to reproduce even that).
+    import subprocess, sys
+    ref_dir = os.path.join(os.path.dirname(HERE), "oracle", "_ref")
+    sac, sac_gpu = os.path.join(ref_dir, "sac"), os.path.join(ref_dir, "sac_gpu")
+    if not (os.path.exists(sac) and os.path.exists(sac_gpu)):
+        pytest.skip("oracle/_ref programs not built")
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    from make_sacfile import wav_bytes
+    rate, n = 2000, 20000
+    L, R = stereo_clip(501, n, rate=rate)
+    wav = tmp_path / "in.wav"
+    wav.write_bytes(wav_bytes(L, R, rate))
+    run = lambda exe, *a, env=None: subprocess.run([exe, *a], check=True, stdout=subprocess.DEVNULL, timeout=300, env=env)
+    run(sac, "--encode", flag, str(wav), str(tmp_path / "ref.sac"))
+    run(sac_gpu, "--encode", flag, str(wav), str(tmp_path / "gpu.sac"))
+    want = (tmp_path / "ref.sac").read_bytes()
+    assert (tmp_path / "gpu.sac").read_bytes() == want
+    if prof == 2:   # Optimize indexes 8 coefficients (codec.cpp:389): high only
+        run(sac_gpu, "--encode", flag, str(wav), str(tmp_path / "gpuopt.sac"), env=dict(os.environ, SAC_GPU_OPTIMIZE="1"))
+        assert (tmp_path / "gpuopt.sac").read_bytes() == want
+    run(sac, "--decode", str(tmp_path / "ref.sac"), str(tmp_path / "ref.wav"))
+    run(sac_gpu, "--decode", str(tmp_path / "ref.sac"), str(tmp_path / "gpu.wav"))
+    assert (tmp_path / "gpu.wav").read_bytes() == (tmp_path / "ref.wav").read_bytes()
+    if prof != 2:
+        assert (tmp_path / "gpu.wav").read_bytes() == wav.read_bytes()
