@@ -16,6 +16,7 @@
 // chains run on the matrix pipe as *adders*, not as a GEMM.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "jobs.h"
 
 // ------------------------------------------------------------------------------------------
@@ -139,16 +140,19 @@ __device__ __forceinline__ double mfma_pass32(uint32_t addr, double acc) {
 }
 #undef MF
 
+#ifndef DPP_BC
+#define DPP_BC true
+#endif
 // Lane i of every 16-lane row receives the value of lane i-O of the same row (0. for i < O): DPP row_shr.
 template <int O>
 __device__ __forceinline__ double row_shr(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(0, lo, 0x110 + O, 0xf, 0xf, false);
-  hi = __builtin_amdgcn_update_dpp(0, hi, 0x110 + O, 0xf, 0xf, false);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x110 + O, 0xf, 0xf, DPP_BC);  // (bound_ctrl: the zero comes from the DPP unit, no register to clear first)
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x110 + O, 0xf, 0xf, DPP_BC);
   return __hiloint2double(hi, lo);
 }
 template <int O>
-__device__ __forceinline__ int row_shr_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x110 + O, 0xf, 0xf, false); }
+__device__ __forceinline__ int row_shr_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x110 + O, 0xf, 0xf, DPP_BC); }
 // Inclusive prefix sum over each 16-lane row (tree order: only ever used as a guess)
 __device__ __forceinline__ double row_prefix16(double v) {
   v += row_shr<1>(v);
@@ -195,9 +199,22 @@ __device__ __forceinline__ int ulp_shift(int v, int ea, int eb) {  // offset in 
 //         ones (each round fixes at least one boundary).
 // Everything before P2 only affects speed; exactness rests on P2 alone.
 // ------------------------------------------------------------------------------------------
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+  if constexpr (B < E) { f(std::integral_constant<int, B>{}); static_for<B + 1, E>(f); }
+}
+#ifndef SPEC_LEANSLOW
+#define SPEC_LEANSLOW 1
+#endif
 template <int NSEG, int STEPS, int SEGP>
 __device__ __forceinline__ double spec_exact_sum(uint32_t prods_addr, int (*sJ)[16], double *sX1, const double *sA, int group,
-                                                 bool walker, int dbg, long long &rounds, const int lane, int *hist = nullptr) {
+                                                 bool walker, int dbg, long long &rounds, const int lane, int *hist = nullptr, long long *spx = nullptr) {
+#ifdef L1_PROF  // walker's clocks (tools/l1_phases.py): table load | walk | start values + shuffles | verification pass | rest
+  long long spT = clock64();
+#define SPX_TICK(i) { if (spx) { const long long now_ = clock64(); spx[i] += now_ - spT; spT = now_; } }
+#else
+#define SPX_TICK(i)
+#endif
   constexpr int NB = NSEG - 1;  // last boundary = input of the last segment
   static_assert(STEPS == 32, "one pass = 32 MFMA steps");
   auto pass = [](uint32_t ad, double c0) { return mfma_pass32(ad, c0); };
@@ -206,6 +223,7 @@ __device__ __forceinline__ double spec_exact_sum(uint32_t prods_addr, int (*sJ)[
   int walk_its = 0;
   const uint32_t paddr = prods_addr + (uint32_t)(jA * SEGP + kA) * 8u;
   double gBase = 0., gU = 0., gIU = 0.;  // lane l: boundary (l & 15)
+  int ex = 0, ksp = 0, ksn = 0, krn = 0;
   if (group >= 0) {
     const double A = jA < NSEG ? sA[jA] : 0.;
     double sh = row_prefix16(A);  // any order: only a guess
@@ -217,64 +235,69 @@ __device__ __forceinline__ double spec_exact_sum(uint32_t prods_addr, int (*sJ)[
     const double stv = __shfl(gBase, jD) + (double)m16 * __shfl(gU, jD);
     const int nbD = jD < NB ? jD + 1 : NB;
     const double nB = __shfl(gBase, nbD), nIU = __shfl(gIU, nbD);
+    if (walker) {
+      // the walk's conversion of an off-grid offset from boundary l's ulps to boundary l + 1's (ulp_shift), as three numbers per
+      // boundary: (hi << ksp) + krn >> ksn. Computed here, in the shadow of the shuffles, for all boundaries at once.
+      ex = (__double2hiint(gU) >> 20) & 0x7ff;                                        // exponent field of the ulp at boundary jA (0: no grid)
+      const int exn = __builtin_amdgcn_update_dpp(0, ex, 0x101, 0xf, 0xf, false);   // ... at boundary jA + 1 (row_shl:1)
+      int ks = (ex && exn) ? ex - exn : 0;
+      ks = ks > 31 ? 31 : (ks < -31 ? -31 : ks);
+      ksp = max(ks, 0); ksn = max(-ks, 0); krn = ksn ? 1 << (ksn - 1) : 0;
+    }
     const double o = pass(paddr, stv);
     sJ[jD][m16] = (jD < NB) ? (int)((o - nB) * nIU) : 0;
     if (jD == 0 && m16 == 0) *sX1 = o;  // segment 0 summed from +0: x_1, exact
   }
+  SPX_TICK(0)
   __syncthreads();
+  SPX_TICK(1)
   double res = 0.;
   if (walker) {
-    // lane l (every 16-lane row alike): boundary jA = l & 15; d = offset of x_jA on its candidate grid
-    const int ex = (__double2hiint(gU) >> 20) & 0x7ff;                         // exponent field of the ulp at boundary jA (0: no grid)
-    const int exn = __builtin_amdgcn_update_dpp(0, ex, 0x101, 0xf, 0xf, false);  // ... at boundary jA + 1 (row_shl:1)
-    // offsets of different boundaries count ulps of different binades: sh = log2(own ulp / finest ulp of the row), so
-    // that y = d << sh is one common unit in which a segment adds a constant to first order (a table is a shift by a
-    // constant in that unit unless partial sums leave the binades of its two ends)
-    int emin = (ex && jA >= 1 && jA <= NB) ? ex : 4095;
-    emin = min(emin, __builtin_amdgcn_update_dpp(emin, emin, 0x121, 0xf, 0xf, false));  // row_ror:1,2,4,8: all-reduce
-    emin = min(emin, __builtin_amdgcn_update_dpp(emin, emin, 0x122, 0xf, 0xf, false));
-    emin = min(emin, __builtin_amdgcn_update_dpp(emin, emin, 0x124, 0xf, 0xf, false));
-    emin = min(emin, __builtin_amdgcn_update_dpp(emin, emin, 0x128, 0xf, 0xf, false));
-    const int sh = ex ? min(ex - emin, 16) : 0;
-    const int shn = __builtin_amdgcn_update_dpp(0, sh, 0x101, 0xf, 0xf, false);
-    const int rnd = sh ? 1 << (sh - 1) : 0;
-    double x = 0.;  // x_0 = +0 exactly
+    // the 15 x 16 table in four registers: boundary l's row in lanes 16 * (l & 3) + m of tb[l >> 2]
+    const int *sJf = &sJ[0][0];
+    const int tb0 = sJf[lane], tb1 = sJf[64 + lane], tb2 = sJf[128 + lane], tb3 = sJf[192 + lane];
+    double x = 0.;  // lane l (row 0): x_l, the input of segment l; x_0 = +0 exactly
     if (jA == 1) x = *sX1;
-    int d = 8;
-    int sp = 1;            // boundaries <= sp are exact
-    int sd = sJ[0][0];     // offset of x_sp on boundary sp's grid
+    int d = 8;                                       // lane l (row 0): offset of x_l on its candidate grid
+    int sp = 1;                                      // boundaries <= sp are exact
+    int sd = __builtin_amdgcn_readlane(tb0, 0);      // offset of x_sp on boundary sp's grid
+    SPX_TICK(2)
     for (int guard = 0; guard < 17; guard++) {
-      // ---- walk: d_{l+1} = step_l(d_l) for l >= sp, solved for all boundaries at once: with inc_l = y(step_l(d_l)) -
-      // y(d_l) evaluated at the current estimates, y_l <- y_sp + sum_{sp <= i < l} inc_i (DPP prefix). A fixed point
-      // is the sequential walk (y is exact both ways there); every iteration makes at least one more boundary final.
+      // ---- walk: d_{l+1} = step_l(d_l) for l >= sp, one boundary after the other on the scalar unit: the offset lives in an
+      // SGPR, a table look-up is a v_readlane with a computed lane (no LDS round trip, no cross-lane work) and the result
+      // goes to lane l + 1 of d with a v_writelane. A step on the grid is 7 instructions and one branch; branches are what
+      // costs here (~25 cycles each, taken or not), so the first walk has no start tests.
+      int ds = sd;
       if (jA == sp) d = sd;
-      const int ysp = sd << __builtin_amdgcn_readlane(sh, sp);
-      for (int it = 0; it < 16; it++) {
-        const int mm = d & 15;
-        int inc = ((sJ[jA][mm] + ulp_shift(d - mm, ex, exn)) << shn) - (d << sh);
-        if (jA < sp || jA >= NB) inc = 0;
-        inc += row_shr_i<1>(inc);
-        inc += row_shr_i<2>(inc);
-        inc += row_shr_i<4>(inc);
-        inc += row_shr_i<8>(inc);
-        const int before = row_shr_i<1>(inc);  // sum over i < jA
-        const int nd = (jA > sp) ? (ysp + before + rnd) >> sh : d;
-        const bool ch = nd != d;
-        d = nd;
+      auto step = [&](auto lc) {
+        constexpr int l = decltype(lc)::value;
+        const int mm = ds & 15, hi = ds - mm;
+        int t = __builtin_amdgcn_readlane(l < 4 ? tb0 : l < 8 ? tb1 : l < 12 ? tb2 : tb3, 16 * (l & 3) + mm);
+#if SPEC_LEANSLOW
+        if (hi) t += ((hi << __builtin_amdgcn_readlane(ksp, l)) + __builtin_amdgcn_readlane(krn, l)) >> __builtin_amdgcn_readlane(ksn, l);
+#else
+        if (hi) t += ulp_shift(hi, __builtin_amdgcn_readlane(ex, l), __builtin_amdgcn_readlane(ex, l + 1));
+#endif
+        ds = __builtin_amdgcn_readfirstlane(t);
+        asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(d) : "s"(ds), "i"(l + 1));
         walk_its++;
-        if (__ballot(ch) == 0ull) break;
-      }
+      };
+      if (guard == 0) static_for<1, NB>(step);
+      else static_for<1, NB>([&](auto lc) { if (decltype(lc)::value >= sp) step(lc); });
+      SPX_TICK(3)
       if (jA > sp) x = gBase + (double)d * gU;
       // ---- P2: verify every boundary
       const double xs = __shfl(x, jD);
       const double xn = __shfl(x, jD < NB ? jD + 1 : NB);
+      SPX_TICK(4)
       res = pass(paddr, xs);
+      SPX_TICK(5)
       const bool bad = (jD < NB) && (__double_as_longlong(res) != __double_as_longlong(xn));
       const unsigned long long mask = __ballot(bad);
       rounds++;
 #ifdef SACOPT_ABLATE
       if (hist && mask == 0ull) {  // statistics (tools/ongrid.py): how far from the guess the exact boundary values lie
-        const bool inb = jA >= 1 && jA <= NB;
+        const bool inb = lane < 16 && jA >= 1 && jA <= NB;
         const double q = (x - gBase) * gIU;
         const bool ongrid = !inb || (ex != 0 && q == (double)(long long)q && gBase + q * gU == x);
         int dev = (inb && ongrid) ? abs((int)q - 8) : 0;
@@ -298,6 +321,7 @@ __device__ __forceinline__ double spec_exact_sum(uint32_t prods_addr, int (*sJ)[
       sd = __builtin_amdgcn_readfirstlane((int)((xt - bq) * iq));
     }
     if (dbg & 1024) rounds += (long long)walk_its << 32;
+    SPX_TICK(6)
   }
   return res;  // chain NB lives in D lanes 16*(NB&3) + 4*(NB>>2) + {0..3}
 }
@@ -680,10 +704,12 @@ __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs
   // that tail runs under the older waves' vector work (same-run A/B: 6.70k -> 6.62k cycles per sample)
   if (wave >= 12) __builtin_amdgcn_s_setprio(3); else if (wave >= 8) __builtin_amdgcn_s_setprio(2); else if (wave >= 4) __builtin_amdgcn_s_setprio(1);
 #ifdef L1_PROF  // phase clocks of every wave (tools/l1_phases.py): products | P1 | walk + verification | update, until its barrier
-  long long pf[4] = {0, 0, 0, 0}, pfT = clock64();
+  long long pf[4] = {0, 0, 0, 0}, pfT = clock64(), spxv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define L1_SPX , spxv
 #define L1_TICK(i) { const long long now_ = clock64(); pf[i] += now_ - pfT; pfT = now_; }
 #else
 #define L1_TICK(i)
+#define L1_SPX
 #endif
 
   auto flush = [&](int tb, int te) {  // p and val[k+1] = x - p (CalcError, profile.cpp:141-148) for times [tb, te)
@@ -740,7 +766,7 @@ __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs
     L1_TICK(0)
     __syncthreads();
     // ---- pred = 0.; for i: pred += w[i]*hist[i]  -- strict order (spec_exact_sum: waves 0..3 sum candidates, wave 0 verifies)
-    const double res = spec_exact_sum<NSEG, SEG / 4, SEGP>((uint32_t)(uintptr_t)&prods[0], sJ, &sX1, sA, wave < 4 ? wave : -1, wave == 0, dbg, rounds, lane, hist);
+    const double res = spec_exact_sum<NSEG, SEG / 4, SEGP>((uint32_t)(uintptr_t)&prods[0], sJ, &sX1, sA, wave < 4 ? wave : -1, wave == 0, dbg, rounds, lane, hist L1_SPX);
     if (wave == 0 && lane == 16 * ((NSEG - 1) & 3) + 4 * ((NSEG - 1) >> 2)) {
       predv = res;
       pbuf[t & (CH - 1)] = res;
@@ -763,7 +789,7 @@ __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs
   if (tend > t0) flush((tend - 1) & ~(CH - 1), tend);
 #ifdef L1_PROF
   __syncthreads();
-  if (lane == 0 && tend - t0 >= 64) { for (int i = 0; i < 4; i++) pout[t0 + 4 * wave + i] = (double)pf[i]; }
+  if (lane == 0 && tend - t0 >= 128) { for (int i = 0; i < 4; i++) pout[t0 + 4 * wave + i] = (double)pf[i]; if (wave == 0) for (int i = 0; i < 8; i++) pout[t0 + 64 + i] = (double)spxv[i]; }
 #endif
   if (dbg & 128) {  // DEBUG: number of P2 passes
     __syncthreads();
