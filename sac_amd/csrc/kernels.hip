@@ -170,12 +170,6 @@ __device__ __forceinline__ double ulp_pow2(double x, double *inv) {
   return __hiloint2double((e - 52) << 20, 0);           // 2^(e-1023-52)
 }
 
-__device__ __forceinline__ int ulp_shift(int v, int ea, int eb) {  // offset in ulps 2^ea -> ulps 2^eb (guess only)
-  int ks = (ea && eb) ? ea - eb : 0;
-  ks = ks > 31 ? 31 : (ks < -31 ? -31 : ks);
-  return ks >= 0 ? (int)((uint32_t)v << ks) : ((v + (1 << (-ks - 1))) >> (-ks));  // to nearest: the likelier of the two outcomes
-}
-
 // ------------------------------------------------------------------------------------------
 // Speculative exact summation of one chain of NSEG segments x 4*STEPS products in LDS (segment stride SEGP
 // doubles starting at LDS byte address prods_addr; chains NSEG..15 of the MFMA passes idle). Called by every
@@ -189,10 +183,14 @@ __device__ __forceinline__ int ulp_shift(int v, int ea, int eb) {  // offset in 
 //         candidate 4w + c. Each output is stored as its offset on the next boundary's candidate grid:
 //         sJ[j][m] = offset at boundary j+1 given offset m at boundary j.
 //   walk  d_{l+1} = step_l(d_l) from the exact x_1, step_l(d) = sJ[l][d & 15] + (d - (d & 15)) converted to the
-//         next boundary's binade: offsets outside 0..15 are extended periodically (a shift by 16q ulps) -- a
+//         next boundary's binade (to nearest): offsets outside 0..15 are extended periodically (a shift by 16q ulps) -- a
 //         guess, but a good one: shifts by high powers of two survive the coarser binades a segment's partial
 //         sums pass through (4 candidates / shifts by 4q failed on 30-45 % of the samples, 16 fail on 5-9 %).
-//         The recursion is solved for all boundaries at once by a fixed-point iteration on DPP prefix sums.
+//         The walker holds the whole table in four registers and walks on the scalar unit: the offset is an SGPR,
+//         a look-up a v_readlane with a computed lane, the conversion three per-boundary numbers (shift left, rounding
+//         term, shift right) computed for all boundaries at once before the pass. (Round 1 solved the recursion for all
+//         boundaries at once by a fixed-point iteration on DPP prefix sums with LDS look-ups, 6.5 iterations of ~35
+//         vector instructions: 1.2k cycles more per sample.)
 //   P2    every segment re-summed exactly from its walked input; each output must EQUAL the next walked
 //         input bit for bit. By induction from x_0 = +0 the last output then IS the sequential sum. A
 //         mismatch pins the first wrong boundary to the exact value just computed and re-walks the later
@@ -203,9 +201,6 @@ template <int B, int E, class F>
 __device__ __forceinline__ void static_for(F &&f) {
   if constexpr (B < E) { f(std::integral_constant<int, B>{}); static_for<B + 1, E>(f); }
 }
-#ifndef SPEC_LEANSLOW
-#define SPEC_LEANSLOW 1
-#endif
 template <int NSEG, int STEPS, int SEGP>
 __device__ __forceinline__ double spec_exact_sum(uint32_t prods_addr, int (*sJ)[16], double *sX1, const double *sA, int group,
                                                  bool walker, int dbg, long long &rounds, const int lane, int *hist = nullptr, long long *spx = nullptr) {
@@ -236,8 +231,8 @@ __device__ __forceinline__ double spec_exact_sum(uint32_t prods_addr, int (*sJ)[
     const int nbD = jD < NB ? jD + 1 : NB;
     const double nB = __shfl(gBase, nbD), nIU = __shfl(gIU, nbD);
     if (walker) {
-      // the walk's conversion of an off-grid offset from boundary l's ulps to boundary l + 1's (ulp_shift), as three numbers per
-      // boundary: (hi << ksp) + krn >> ksn. Computed here, in the shadow of the shuffles, for all boundaries at once.
+      // the walk's conversion of an off-grid offset from boundary l's ulps to boundary l + 1's, as three numbers per boundary:
+      // ((hi << ksp) + krn) >> ksn, to nearest (a guess only). Computed here, in the shadow of the shuffles, for all boundaries at once.
       ex = (__double2hiint(gU) >> 20) & 0x7ff;                                        // exponent field of the ulp at boundary jA (0: no grid)
       const int exn = __builtin_amdgcn_update_dpp(0, ex, 0x101, 0xf, 0xf, false);   // ... at boundary jA + 1 (row_shl:1)
       int ks = (ex && exn) ? ex - exn : 0;
@@ -273,11 +268,7 @@ __device__ __forceinline__ double spec_exact_sum(uint32_t prods_addr, int (*sJ)[
         constexpr int l = decltype(lc)::value;
         const int mm = ds & 15, hi = ds - mm;
         int t = __builtin_amdgcn_readlane(l < 4 ? tb0 : l < 8 ? tb1 : l < 12 ? tb2 : tb3, 16 * (l & 3) + mm);
-#if SPEC_LEANSLOW
         if (hi) t += ((hi << __builtin_amdgcn_readlane(ksp, l)) + __builtin_amdgcn_readlane(krn, l)) >> __builtin_amdgcn_readlane(ksn, l);
-#else
-        if (hi) t += ulp_shift(hi, __builtin_amdgcn_readlane(ex, l), __builtin_amdgcn_readlane(ex, l + 1));
-#endif
         ds = __builtin_amdgcn_readfirstlane(t);
         asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(d) : "s"(ds), "i"(l + 1));
         walk_its++;
