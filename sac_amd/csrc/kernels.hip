@@ -176,7 +176,7 @@ __device__ __forceinline__ double ulp_pow2(double x, double *inv) {
 // wave of the workgroup (it contains a workgroup barrier); `group` in 0..3 marks the four waves that sum
 // candidates for this chain, -1 the bystanders; `walker` is the one candidate wave (group 0) that follows the
 // chain and verifies it. sA[j]: approximate sum of segment j (any order -- the caller's tree reduction).
-// Returns, in the D lanes of chain NSEG-1 of the walker, the strict left-to-right FP64 sum (nlms.h:110-111).
+// Returns, in every lane of the walker, the strict left-to-right FP64 sum (nlms.h:110-111).
 //   P1    the prefix of sA guesses the segment inputs g_j (boundary j = input of segment j). Each candidate
 //         wave sums every segment EXACTLY from 16 candidate inputs g_j + (m-8) ulp: the four columns of the
 //         4x4 MFMA output share their A terms (B == 1) but keep their own C, so wave w, column c carries
@@ -201,10 +201,15 @@ template <int B, int E, class F>
 __device__ __forceinline__ void static_for(F &&f) {
   if constexpr (B < E) { f(std::integral_constant<int, B>{}); static_for<B + 1, E>(f); }
 }
+// Layout: MFMA chain 4*blk + i carries segment 4*i + blk, so that the D-layout lane 16*i + 4*blk + col -- the lane that holds the
+// accumulator of that chain's candidate column col -- is lane 4*segment + col: the segments lie along the wave in order. The
+// guess (a prefix sum over the segments) is then a DPP scan in the very lanes that need it as MFMA start values, the "next
+// boundary" of a lane is the scan's inclusive value in the same lane, and the walker addresses boundary l as lane 4*l: no
+// cross-lane shuffle (ds_bpermute) anywhere in the function.
 template <int NSEG, int STEPS, int SEGP>
 __device__ __forceinline__ double spec_exact_sum(uint32_t prods_addr, int (*sJ)[16], double *sX1, const double *sA, int group,
                                                  bool walker, int dbg, long long &rounds, const int lane, int *hist = nullptr, long long *spx = nullptr) {
-#ifdef L1_PROF  // walker's clocks (tools/l1_phases.py): table load | walk | start values + shuffles | verification pass | rest
+#ifdef L1_PROF  // walker's clocks (tools/l1_phases.py): guess + candidate pass | barrier | table load | walk | start values | verification pass | rest
   long long spT = clock64();
 #define SPX_TICK(i) { if (spx) { const long long now_ = clock64(); spx[i] += now_ - spT; spT = now_; } }
 #else
@@ -212,36 +217,58 @@ __device__ __forceinline__ double spec_exact_sum(uint32_t prods_addr, int (*sJ)[
 #endif
   constexpr int NB = NSEG - 1;  // last boundary = input of the last segment
   static_assert(STEPS == 32, "one pass = 32 MFMA steps");
-  auto pass = [](uint32_t ad, double c0) { return mfma_pass32(ad, c0); };
-  const int jA = lane & 15, kA = lane >> 4;                      // A-operand lane: chain jA, term 4s+kA at step s
-  const int jD = 4 * ((lane >> 2) & 3) + (lane >> 4);             // chain held by this D-layout lane
+  const int jA = lane & 15, kA = lane >> 4;          // A-operand lane: chain jA, term 4s+kA of its segment at step s
+  const int segA = 4 * (jA & 3) + (jA >> 2);         // ... and the segment that chain carries
+  const int sD = lane >> 2, col = lane & 3;          // D-layout lane: segment sD, candidate column col
   int walk_its = 0;
-  const uint32_t paddr = prods_addr + (uint32_t)(jA * SEGP + kA) * 8u;
-  double gBase = 0., gU = 0., gIU = 0.;  // lane l: boundary (l & 15)
-  int ex = 0, ksp = 0, ksn = 0, krn = 0;
+  const uint32_t paddr = prods_addr + (uint32_t)(segA * SEGP + kA) * 8u;
+  // boundary sD (input of this lane's segment): candidate grid gBase + m * gU; boundary sD + 1 (its output): nB + m * nU
+  double gBase = 0., gU = 0., gIU = 0., nB = 0., nU = 0., nIU = 0.;
+  int ksp = 0, ksn = 0, krn = 0;
   if (group >= 0) {
-    const double A = jA < NSEG ? sA[jA] : 0.;
-    double sh = row_prefix16(A);  // any order: only a guess
-    sh -= A;
-    if (jA == 0) sh = 0.;
-    gU = ulp_pow2(sh, &gIU);
-    gBase = sh - 8. * gU;
-    const int m16 = 4 * group + (lane & 3);
-    const double stv = __shfl(gBase, jD) + (double)m16 * __shfl(gU, jD);
-    const int nbD = jD < NB ? jD + 1 : NB;
-    const double nB = __shfl(gBase, nbD), nIU = __shfl(gIU, nbD);
+    const double A = sD < NSEG ? sA[sD] : 0.;
+    // inclusive prefix over the segments, any order (only a guess): quads of a row, then rows
+    double incl = A;
+    incl += row_shr<4>(incl);
+    incl += row_shr<8>(incl);
+    {
+      int lo = __double2loint(incl), hi = __double2hiint(incl);
+      lo = __builtin_amdgcn_update_dpp(0, lo, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1 and 3
+      hi = __builtin_amdgcn_update_dpp(0, hi, 0x142, 0xA, 0xF, false);
+      incl += __hiloint2double(hi, lo);
+      lo = __double2loint(incl); hi = __double2hiint(incl);
+      lo = __builtin_amdgcn_update_dpp(0, lo, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2 and 3
+      hi = __builtin_amdgcn_update_dpp(0, hi, 0x143, 0xC, 0xF, false);
+      incl += __hiloint2double(hi, lo);
+    }
+    // the previous segment's inclusive value, MOVED (not recomputed: both neighbours must use the same bits for a boundary):
+    // quads 1..3 from the quad before (row_shr:4), quad 0 of rows 1..3 from the last lane of the row before (row_bcast:15)
+    double prev;
+    {
+      int lo = __double2loint(incl), hi = __double2hiint(incl);
+      int plo = __builtin_amdgcn_update_dpp(0, lo, 0x114, 0xF, 0xE, false);
+      int phi = __builtin_amdgcn_update_dpp(0, hi, 0x114, 0xF, 0xE, false);
+      plo = __builtin_amdgcn_update_dpp(plo, lo, 0x142, 0xE, 0x1, false);
+      phi = __builtin_amdgcn_update_dpp(phi, hi, 0x142, 0xE, 0x1, false);
+      prev = __hiloint2double(phi, plo);
+    }
+    gU = ulp_pow2(prev, &gIU);
+    gBase = prev - 8. * gU;
+    nU = ulp_pow2(incl, &nIU);
+    nB = incl - 8. * nU;
+    const int m16 = 4 * group + col;
+    const double stv = gBase + (double)m16 * gU;
     if (walker) {
       // the walk's conversion of an off-grid offset from boundary l's ulps to boundary l + 1's, as three numbers per boundary:
-      // ((hi << ksp) + krn) >> ksn, to nearest (a guess only). Computed here, in the shadow of the shuffles, for all boundaries at once.
-      ex = (__double2hiint(gU) >> 20) & 0x7ff;                                        // exponent field of the ulp at boundary jA (0: no grid)
-      const int exn = __builtin_amdgcn_update_dpp(0, ex, 0x101, 0xf, 0xf, false);   // ... at boundary jA + 1 (row_shl:1)
+      // ((hi << ksp) + krn) >> ksn, to nearest (a guess only); lane 4*l holds those of the step from boundary l
+      const int ex = (__double2hiint(gU) >> 20) & 0x7ff, exn = (__double2hiint(nU) >> 20) & 0x7ff;  // exponent fields of the ulps (0: no grid)
       int ks = (ex && exn) ? ex - exn : 0;
       ks = ks > 31 ? 31 : (ks < -31 ? -31 : ks);
       ksp = max(ks, 0); ksn = max(-ks, 0); krn = ksn ? 1 << (ksn - 1) : 0;
     }
-    const double o = pass(paddr, stv);
-    sJ[jD][m16] = (jD < NB) ? (int)((o - nB) * nIU) : 0;
-    if (jD == 0 && m16 == 0) *sX1 = o;  // segment 0 summed from +0: x_1, exact
+    const double o = mfma_pass32(paddr, stv);
+    if (sD < NSEG) sJ[sD][m16] = (sD < NB) ? (int)((o - nB) * nIU) : 0;
+    if (sD == 0 && m16 == 0) *sX1 = o;  // segment 0 summed from +0: x_1, exact
   }
   SPX_TICK(0)
   __syncthreads();
@@ -251,48 +278,48 @@ __device__ __forceinline__ double spec_exact_sum(uint32_t prods_addr, int (*sJ)[
     // the 15 x 16 table in four registers: boundary l's row in lanes 16 * (l & 3) + m of tb[l >> 2]
     const int *sJf = &sJ[0][0];
     const int tb0 = sJf[lane], tb1 = sJf[64 + lane], tb2 = sJf[128 + lane], tb3 = sJf[192 + lane];
-    double x = 0.;  // lane l (row 0): x_l, the input of segment l; x_0 = +0 exactly
-    if (jA == 1) x = *sX1;
-    int d = 8;                                       // lane l (row 0): offset of x_l on its candidate grid
+    const double x1 = *sX1;
+    // lane 4*s: xs = x_s, the input of segment s, xn = x_{s+1}, the output it must produce; x_0 = +0 and x_1 are exact
+    double xs = sD == 1 ? x1 : 0., xn = sD == 0 ? x1 : 0.;
+    int dS = 8, dE = 8;                              // lane 4*s: offsets of x_s / x_{s+1} on their candidate grids
     int sp = 1;                                      // boundaries <= sp are exact
     int sd = __builtin_amdgcn_readlane(tb0, 0);      // offset of x_sp on boundary sp's grid
     SPX_TICK(2)
     for (int guard = 0; guard < 17; guard++) {
       // ---- walk: d_{l+1} = step_l(d_l) for l >= sp, one boundary after the other on the scalar unit: the offset lives in an
       // SGPR, a table look-up is a v_readlane with a computed lane (no LDS round trip, no cross-lane work) and the result
-      // goes to lane l + 1 of d with a v_writelane. A step on the grid is 7 instructions and one branch; branches are what
-      // costs here (~25 cycles each, taken or not), so the first walk has no start tests.
+      // goes to lanes 4*(l+1) (as that segment's input) and 4*l (as this segment's expected output) by v_writelane. Branches
+      // are what costs here (~25 cycles each, taken or not), so the first walk has no start tests.
       int ds = sd;
-      if (jA == sp) d = sd;
       auto step = [&](auto lc) {
         constexpr int l = decltype(lc)::value;
         const int mm = ds & 15, hi = ds - mm;
         int t = __builtin_amdgcn_readlane(l < 4 ? tb0 : l < 8 ? tb1 : l < 12 ? tb2 : tb3, 16 * (l & 3) + mm);
-        if (hi) t += ((hi << __builtin_amdgcn_readlane(ksp, l)) + __builtin_amdgcn_readlane(krn, l)) >> __builtin_amdgcn_readlane(ksn, l);
+        if (hi) t += ((hi << __builtin_amdgcn_readlane(ksp, 4 * l)) + __builtin_amdgcn_readlane(krn, 4 * l)) >> __builtin_amdgcn_readlane(ksn, 4 * l);
         ds = __builtin_amdgcn_readfirstlane(t);
-        asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(d) : "s"(ds), "i"(l + 1));
+        asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(dS) : "s"(ds), "i"(4 * (l + 1)));
+        asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(dE) : "s"(ds), "i"(4 * l));
         walk_its++;
       };
       if (guard == 0) static_for<1, NB>(step);
       else static_for<1, NB>([&](auto lc) { if (decltype(lc)::value >= sp) step(lc); });
       SPX_TICK(3)
-      if (jA > sp) x = gBase + (double)d * gU;
-      // ---- P2: verify every boundary
-      const double xs = __shfl(x, jD);
-      const double xn = __shfl(x, jD < NB ? jD + 1 : NB);
+      if (sD > sp) xs = gBase + (double)dS * gU;
+      if (sD >= sp) xn = nB + (double)dE * nU;
+      // ---- P2: verify every boundary (column 0 of every segment; the other columns sum from whatever they hold)
       SPX_TICK(4)
-      res = pass(paddr, xs);
+      res = mfma_pass32(paddr, xs);
       SPX_TICK(5)
-      const bool bad = (jD < NB) && (__double_as_longlong(res) != __double_as_longlong(xn));
+      const bool bad = (col == 0) && (sD < NB) && (__double_as_longlong(res) != __double_as_longlong(xn));
       const unsigned long long mask = __ballot(bad);
       rounds++;
 #ifdef SACOPT_ABLATE
       if (hist && mask == 0ull) {  // statistics (tools/ongrid.py): how far from the guess the exact boundary values lie
-        const bool inb = lane < 16 && jA >= 1 && jA <= NB;
-        const double q = (x - gBase) * gIU;
-        const bool ongrid = !inb || (ex != 0 && q == (double)(long long)q && gBase + q * gU == x);
+        const bool inb = col == 0 && sD >= 1 && sD <= NB;
+        const double q = (xs - gBase) * gIU;
+        const bool ongrid = !inb || (gU != 0. && q == (double)(long long)q && gBase + q * gU == xs);
         int dev = (inb && ongrid) ? abs((int)q - 8) : 0;
-        for (int o = 1; o < 16; o <<= 1) dev = max(dev, __shfl_xor(dev, o));
+        for (int o = 1; o < 64; o <<= 1) dev = max(dev, __shfl_xor(dev, o));
         const bool allgrid = __ballot(!ongrid) == 0ull;
         if (lane == 0) {
           const int bin = !allgrid ? 7 : dev <= 7 ? 0 : dev <= 15 ? 1 : dev <= 23 ? 2 : dev <= 31 ? 3 : dev <= 63 ? 4 : dev <= 127 ? 5 : 6;
@@ -302,21 +329,21 @@ __device__ __forceinline__ double spec_exact_sum(uint32_t prods_addr, int (*sJ)[
       }
 #endif
       if (mask == 0ull || (dbg & 16)) break;
-      int f = 0;  // first failing segment (D-layout lane of chain j: 16*(j&3) + 4*(j>>2))
-      while (f < NB && !((mask >> (16 * (f & 3) + 4 * (f >> 2))) & 1ull)) f++;
-      f = __builtin_amdgcn_readfirstlane(f);
-      const double xt = bcast(res, 16 * (f & 3) + 4 * (f >> 2));  // exact x_{f+1}
-      if (jA == f + 1) x = xt;
+      const int f = __builtin_amdgcn_readfirstlane((int)(__builtin_ctzll(mask) >> 2));  // first failing segment
+      const double xt = bcast(res, 4 * f);  // exact x_{f+1}
+      if (sD == f + 1) xs = xt;
+      if (sD == f) xn = xt;
       sp = f + 1;
-      const double bq = bcast(gBase, f + 1), iq = bcast(gIU, f + 1);
+      const double bq = bcast(nB, 4 * f), iq = bcast(nIU, 4 * f);
       sd = __builtin_amdgcn_readfirstlane((int)((xt - bq) * iq));
     }
     if (dbg & 1024) rounds += (long long)walk_its << 32;
+    res = bcast(res, 4 * NB);  // the last segment's output: the sum (to every lane of the walker)
     SPX_TICK(6)
   }
-  return res;  // chain NB lives in D lanes 16*(NB&3) + 4*(NB>>2) + {0..3}
+  return res;
 }
-
+#define SPEC_RESULT_LANE(NSEG) 0  // the sum is returned to every lane of the walker
 // ------------------------------------------------------------------------------------------
 // LMSADA2 stereo pair (src/pred/nlms.h:96-139), driven as StereoHigh/StereoNormal drive it
 // (src/profile.cpp:126-148,176-186):
@@ -481,7 +508,7 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
       const int sc = wave & 1, grp = wave < 8 ? (wave >> 1) : -1;
       long long rounds_ = 0;
       const double res = spec_exact_sum<NSEG, SEG / 4, SEGP>((uint32_t)(uintptr_t)&prods[sc][0], sJ[sc], &sX1[sc], sA[sc], grp, grp == 0, dbg, rounds_, lane);
-      if (grp == 0 && lane == 16 * ((NSEG - 1) & 3) + 4 * ((NSEG - 1) >> 2)) {
+      if (grp == 0 && lane == SPEC_RESULT_LANE(NSEG)) {
         predv[sc] = res;
         pbuf[sc][t & (CH - 1)] = res;
       }
@@ -758,7 +785,7 @@ __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs
     __syncthreads();
     // ---- pred = 0.; for i: pred += w[i]*hist[i]  -- strict order (spec_exact_sum: waves 0..3 sum candidates, wave 0 verifies)
     const double res = spec_exact_sum<NSEG, SEG / 4, SEGP>((uint32_t)(uintptr_t)&prods[0], sJ, &sX1, sA, wave < 4 ? wave : -1, wave == 0, dbg, rounds, lane, hist L1_SPX);
-    if (wave == 0 && lane == 16 * ((NSEG - 1) & 3) + 4 * ((NSEG - 1) >> 2)) {
+    if (wave == 0 && lane == SPEC_RESULT_LANE(NSEG)) {
       predv = res;
       pbuf[t & (CH - 1)] = res;
     }
@@ -1527,7 +1554,7 @@ __global__ __launch_bounds__(256) void k_sumkat(const double *__restrict__ x, do
     __syncthreads();
     long long rounds = 0;
     const double res = spec_exact_sum<NSEG, SEG / 4, SEGP>((uint32_t)(uintptr_t)&prods[0], sJ, &sX1, sA, wave, wave == 0, 0, rounds, lane);
-    if (wave == 0 && lane == 16 * ((NSEG - 1) & 3) + 4 * ((NSEG - 1) >> 2)) out[blockIdx.x] = res;
+    if (wave == 0 && lane == SPEC_RESULT_LANE(NSEG)) out[blockIdx.x] = res;
   } else {
     constexpr int T4 = N / 4, TP = N + 4;
     for (int i = tid; i < N; i += 256) { prods[i] = xv[i]; prods[TP + i] = xv[i]; }  // the stages' two-channel operand layout

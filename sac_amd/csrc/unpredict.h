@@ -268,7 +268,7 @@ __global__ __launch_bounds__(UN_NT) void k_unpredict(const UnJob *__restrict__ j
       if constexpr (BIG) {
         const double res = spec_exact_sum<NSEG, SEG / 4, SEGP>((uint32_t)(uintptr_t)&prodsB[0], sJ, &sX1, sA, wave < 4 ? wave : -1,
                                                                wave == 0, 0, rounds, lane);
-        if (wave == 0 && lane == 16 * ((NSEG - 1) & 3) + 4 * ((NSEG - 1) >> 2)) pst[1] = res;
+        if (wave == 0 && lane == SPEC_RESULT_LANE(NSEG)) pst[1] = res;
       }
       if (LMS && wave == 5) {  // SIMD 1 (waves go round the four SIMDs): wave 0's verification pass has SIMD 0's matrix pipe to itself
         const double acc = mfma_chain_lds<6>((uint32_t)(uintptr_t)&prodsM[mk]);
