@@ -140,6 +140,45 @@ __device__ __forceinline__ double mfma_pass32(uint32_t addr, double acc) {
 }
 #undef MF
 
+// mfma_pass32 that KEEPS the 32 operands of every lane (64 VGPRs), and the same pass from kept operands: no LDS access at all.
+// For a wave that sums the same products twice (k_lms1c's walker: candidate pass, then verification while the other waves
+// are busy in the LDS).
+struct Op32 { double v[32]; };
+__device__ __forceinline__ double mfma_pass32_keep(uint32_t addr, double acc, Op32 &p) {
+  double one = 1.0;
+  asm volatile(
+      "ds_read_b64 %0, %33 offset:0\n" "ds_read_b64 %1, %33 offset:32\n" "ds_read_b64 %2, %33 offset:64\n" "ds_read_b64 %3, %33 offset:96\n" "ds_read_b64 %4, %33 offset:128\n" "ds_read_b64 %5, %33 offset:160\n" "ds_read_b64 %6, %33 offset:192\n" "ds_read_b64 %7, %33 offset:224\n"
+      "ds_read_b64 %8, %33 offset:256\n" "ds_read_b64 %9, %33 offset:288\n" "ds_read_b64 %10, %33 offset:320\n" "ds_read_b64 %11, %33 offset:352\n" "ds_read_b64 %12, %33 offset:384\n" "ds_read_b64 %13, %33 offset:416\n" "ds_read_b64 %14, %33 offset:448\n" "ds_read_b64 %15, %33 offset:480\n"
+      "s_waitcnt lgkmcnt(8)\n s_nop 1\n"
+      "v_mfma_f64_4x4x4_4b_f64 %32, %0, %34, %32\n s_nop 3\n" "v_mfma_f64_4x4x4_4b_f64 %32, %1, %34, %32\n s_nop 3\n" "v_mfma_f64_4x4x4_4b_f64 %32, %2, %34, %32\n s_nop 3\n" "v_mfma_f64_4x4x4_4b_f64 %32, %3, %34, %32\n s_nop 3\n" "v_mfma_f64_4x4x4_4b_f64 %32, %4, %34, %32\n s_nop 3\n" "v_mfma_f64_4x4x4_4b_f64 %32, %5, %34, %32\n s_nop 3\n" "v_mfma_f64_4x4x4_4b_f64 %32, %6, %34, %32\n s_nop 3\n" "v_mfma_f64_4x4x4_4b_f64 %32, %7, %34, %32\n s_nop 3\n"
+      "ds_read_b64 %16, %33 offset:512\n" "ds_read_b64 %17, %33 offset:544\n" "ds_read_b64 %18, %33 offset:576\n" "ds_read_b64 %19, %33 offset:608\n" "ds_read_b64 %20, %33 offset:640\n" "ds_read_b64 %21, %33 offset:672\n" "ds_read_b64 %22, %33 offset:704\n" "ds_read_b64 %23, %33 offset:736\n"
+      "s_waitcnt lgkmcnt(8)\n s_nop 1\n"
+      "v_mfma_f64_4x4x4_4b_f64 %32, %8, %34, %32\n s_nop 3\n" "v_mfma_f64_4x4x4_4b_f64 %32, %9, %34, %32\n s_nop 3\n" "v_mfma_f64_4x4x4_4b_f64 %32, %10, %34, %32\n s_nop 3\n" "v_mfma_f64_4x4x4_4b_f64 %32, %11, %34, %32\n s_nop 3\n" "v_mfma_f64_4x4x4_4b_f64 %32, %12, %34, %32\n s_nop 3\n" "v_mfma_f64_4x4x4_4b_f64 %32, %13, %34, %32\n s_nop 3\n" "v_mfma_f64_4x4x4_4b_f64 %32, %14, %34, %32\n s_nop 3\n" "v_mfma_f64_4x4x4_4b_f64 %32, %15, %34, %32\n s_nop 3\n"
+      "ds_read_b64 %24, %33 offset:768\n" "ds_read_b64 %25, %33 offset:800\n" "ds_read_b64 %26, %33 offset:832\n" "ds_read_b64 %27, %33 offset:864\n" "ds_read_b64 %28, %33 offset:896\n" "ds_read_b64 %29, %33 offset:928\n" "ds_read_b64 %30, %33 offset:960\n" "ds_read_b64 %31, %33 offset:992\n"
+      "s_waitcnt lgkmcnt(8)\n s_nop 1\n"
+      "v_mfma_f64_4x4x4_4b_f64 %32, %16, %34, %32\n s_nop 3\n" "v_mfma_f64_4x4x4_4b_f64 %32, %17, %34, %32\n s_nop 3\n" "v_mfma_f64_4x4x4_4b_f64 %32, %18, %34, %32\n s_nop 3\n" "v_mfma_f64_4x4x4_4b_f64 %32, %19, %34, %32\n s_nop 3\n" "v_mfma_f64_4x4x4_4b_f64 %32, %20, %34, %32\n s_nop 3\n" "v_mfma_f64_4x4x4_4b_f64 %32, %21, %34, %32\n s_nop 3\n" "v_mfma_f64_4x4x4_4b_f64 %32, %22, %34, %32\n s_nop 3\n" "v_mfma_f64_4x4x4_4b_f64 %32, %23, %34, %32\n s_nop 3\n"
+      "s_waitcnt lgkmcnt(0)\n s_nop 1\n"
+      "v_mfma_f64_4x4x4_4b_f64 %32, %24, %34, %32\n s_nop 3\n" "v_mfma_f64_4x4x4_4b_f64 %32, %25, %34, %32\n s_nop 3\n" "v_mfma_f64_4x4x4_4b_f64 %32, %26, %34, %32\n s_nop 3\n" "v_mfma_f64_4x4x4_4b_f64 %32, %27, %34, %32\n s_nop 3\n" "v_mfma_f64_4x4x4_4b_f64 %32, %28, %34, %32\n s_nop 3\n" "v_mfma_f64_4x4x4_4b_f64 %32, %29, %34, %32\n s_nop 3\n" "v_mfma_f64_4x4x4_4b_f64 %32, %30, %34, %32\n s_nop 3\n" "v_mfma_f64_4x4x4_4b_f64 %32, %31, %34, %32\n s_nop 3\n"
+      "s_nop 7\n"
+      : "=&v"(p.v[0]), "=&v"(p.v[1]), "=&v"(p.v[2]), "=&v"(p.v[3]), "=&v"(p.v[4]), "=&v"(p.v[5]), "=&v"(p.v[6]), "=&v"(p.v[7]), "=&v"(p.v[8]), "=&v"(p.v[9]), "=&v"(p.v[10]), "=&v"(p.v[11]), "=&v"(p.v[12]), "=&v"(p.v[13]), "=&v"(p.v[14]), "=&v"(p.v[15]), "=&v"(p.v[16]), "=&v"(p.v[17]), "=&v"(p.v[18]), "=&v"(p.v[19]), "=&v"(p.v[20]), "=&v"(p.v[21]), "=&v"(p.v[22]), "=&v"(p.v[23]), "=&v"(p.v[24]), "=&v"(p.v[25]), "=&v"(p.v[26]), "=&v"(p.v[27]), "=&v"(p.v[28]), "=&v"(p.v[29]), "=&v"(p.v[30]), "=&v"(p.v[31]), "+v"(acc)
+      : "v"(addr), "v"(one)
+      : "memory");
+  return acc;
+}
+__device__ __forceinline__ double mfma_pass32_regs(double acc, const Op32 &p) {
+  double one = 1.0;
+  asm volatile(
+      "s_nop 7\n"  // the start value may come straight from a vector instruction
+      "v_mfma_f64_4x4x4_4b_f64 %0, %1, %33, %0\n s_nop 3\n" "v_mfma_f64_4x4x4_4b_f64 %0, %2, %33, %0\n s_nop 3\n" "v_mfma_f64_4x4x4_4b_f64 %0, %3, %33, %0\n s_nop 3\n" "v_mfma_f64_4x4x4_4b_f64 %0, %4, %33, %0\n s_nop 3\n" "v_mfma_f64_4x4x4_4b_f64 %0, %5, %33, %0\n s_nop 3\n" "v_mfma_f64_4x4x4_4b_f64 %0, %6, %33, %0\n s_nop 3\n" "v_mfma_f64_4x4x4_4b_f64 %0, %7, %33, %0\n s_nop 3\n" "v_mfma_f64_4x4x4_4b_f64 %0, %8, %33, %0\n s_nop 3\n"
+      "v_mfma_f64_4x4x4_4b_f64 %0, %9, %33, %0\n s_nop 3\n" "v_mfma_f64_4x4x4_4b_f64 %0, %10, %33, %0\n s_nop 3\n" "v_mfma_f64_4x4x4_4b_f64 %0, %11, %33, %0\n s_nop 3\n" "v_mfma_f64_4x4x4_4b_f64 %0, %12, %33, %0\n s_nop 3\n" "v_mfma_f64_4x4x4_4b_f64 %0, %13, %33, %0\n s_nop 3\n" "v_mfma_f64_4x4x4_4b_f64 %0, %14, %33, %0\n s_nop 3\n" "v_mfma_f64_4x4x4_4b_f64 %0, %15, %33, %0\n s_nop 3\n" "v_mfma_f64_4x4x4_4b_f64 %0, %16, %33, %0\n s_nop 3\n"
+      "v_mfma_f64_4x4x4_4b_f64 %0, %17, %33, %0\n s_nop 3\n" "v_mfma_f64_4x4x4_4b_f64 %0, %18, %33, %0\n s_nop 3\n" "v_mfma_f64_4x4x4_4b_f64 %0, %19, %33, %0\n s_nop 3\n" "v_mfma_f64_4x4x4_4b_f64 %0, %20, %33, %0\n s_nop 3\n" "v_mfma_f64_4x4x4_4b_f64 %0, %21, %33, %0\n s_nop 3\n" "v_mfma_f64_4x4x4_4b_f64 %0, %22, %33, %0\n s_nop 3\n" "v_mfma_f64_4x4x4_4b_f64 %0, %23, %33, %0\n s_nop 3\n" "v_mfma_f64_4x4x4_4b_f64 %0, %24, %33, %0\n s_nop 3\n"
+      "v_mfma_f64_4x4x4_4b_f64 %0, %25, %33, %0\n s_nop 3\n" "v_mfma_f64_4x4x4_4b_f64 %0, %26, %33, %0\n s_nop 3\n" "v_mfma_f64_4x4x4_4b_f64 %0, %27, %33, %0\n s_nop 3\n" "v_mfma_f64_4x4x4_4b_f64 %0, %28, %33, %0\n s_nop 3\n" "v_mfma_f64_4x4x4_4b_f64 %0, %29, %33, %0\n s_nop 3\n" "v_mfma_f64_4x4x4_4b_f64 %0, %30, %33, %0\n s_nop 3\n" "v_mfma_f64_4x4x4_4b_f64 %0, %31, %33, %0\n s_nop 3\n" "v_mfma_f64_4x4x4_4b_f64 %0, %32, %33, %0\n s_nop 3\n"
+      "s_nop 7\n"
+      : "+v"(acc)
+      : "v"(p.v[0]), "v"(p.v[1]), "v"(p.v[2]), "v"(p.v[3]), "v"(p.v[4]), "v"(p.v[5]), "v"(p.v[6]), "v"(p.v[7]), "v"(p.v[8]), "v"(p.v[9]), "v"(p.v[10]), "v"(p.v[11]), "v"(p.v[12]), "v"(p.v[13]), "v"(p.v[14]), "v"(p.v[15]), "v"(p.v[16]), "v"(p.v[17]), "v"(p.v[18]), "v"(p.v[19]), "v"(p.v[20]), "v"(p.v[21]), "v"(p.v[22]), "v"(p.v[23]), "v"(p.v[24]), "v"(p.v[25]), "v"(p.v[26]), "v"(p.v[27]), "v"(p.v[28]), "v"(p.v[29]), "v"(p.v[30]), "v"(p.v[31]), "v"(one));
+  return acc;
+}
+
 #ifndef DPP_BC
 #define DPP_BC true
 #endif
@@ -205,27 +244,36 @@ __device__ __forceinline__ void static_for(F &&f) {
 // accumulator of that chain's candidate column col -- is lane 4*segment + col: the segments lie along the wave in order. The
 // guess (a prefix sum over the segments) is then a DPP scan in the very lanes that need it as MFMA start values, the "next
 // boundary" of a lane is the scan's inclusive value in the same lane, and the walker addresses boundary l as lane 4*l: no
-// cross-lane shuffle (ds_bpermute) anywhere in the function.
-template <int NSEG, int STEPS, int SEGP>
-__device__ __forceinline__ double spec_exact_sum(uint32_t prods_addr, int (*sJ)[16], double *sX1, const double *sA, int group,
-                                                 bool walker, int dbg, long long &rounds, const int lane, int *hist = nullptr, long long *spx = nullptr) {
-#ifdef L1_PROF  // walker's clocks (tools/l1_phases.py): guess + candidate pass | barrier | table load | walk | start values | verification pass | rest
-  long long spT = clock64();
-#define SPX_TICK(i) { if (spx) { const long long now_ = clock64(); spx[i] += now_ - spT; spT = now_; } }
-#else
-#define SPX_TICK(i)
-#endif
-  constexpr int NB = NSEG - 1;  // last boundary = input of the last segment
-  static_assert(STEPS == 32, "one pass = 32 MFMA steps");
-  const int jA = lane & 15, kA = lane >> 4;          // A-operand lane: chain jA, term 4s+kA of its segment at step s
-  const int segA = 4 * (jA & 3) + (jA >> 2);         // ... and the segment that chain carries
-  const int sD = lane >> 2, col = lane & 3;          // D-layout lane: segment sD, candidate column col
-  int walk_its = 0;
-  const uint32_t paddr = prods_addr + (uint32_t)(segA * SEGP + kA) * 8u;
+// cross-lane shuffle (ds_bpermute) anywhere.
+//
+// The three phases are separate members so that a kernel can put its own work between them (k_lms1c updates with the walk's
+// prediction while the walker verifies it); spec_exact_sum() below is the plain sequence: candidates | barrier | first_walk, verify.
+template <int NSEG, int SEGP>
+struct SpecSum {
+  static constexpr int NB = NSEG - 1;  // last boundary = input of the last segment
+  uint32_t paddr;                      // LDS byte address of this A-operand lane's first term
+  int sD, col;                         // D-layout lane: segment sD, candidate column col
   // boundary sD (input of this lane's segment): candidate grid gBase + m * gU; boundary sD + 1 (its output): nB + m * nU
-  double gBase = 0., gU = 0., gIU = 0., nB = 0., nU = 0., nIU = 0.;
-  int ksp = 0, ksn = 0, krn = 0;
-  if (group >= 0) {
+  double gBase, gU, gIU, nB, nU, nIU;
+  int ksp, ksn, krn;                   // the walk's off-grid conversion (lane 4*l: step from boundary l)
+  int tb0, tb1, tb2, tb3;              // walker: the 15 x 16 table, boundary l's row in lanes 16 * (l & 3) + m of tb[l >> 2]
+  double xs, xn;                       // walker, lane 4*s: x_s, the input of segment s, and x_{s+1}, the output it must produce
+  int dS, dE;                          // walker, lane 4*s: their offsets on the candidate grids
+  int sp, sd;                          // boundaries <= sp are exact; sd = offset of x_sp on its grid
+  int walk_its;
+
+  // P1, the four candidate waves (group 0..3) of the chain. sOut (optional): the last segment's outputs per candidate, as doubles --
+  // what the sum will be if the walk ends on candidate m.
+  // WIDE: the idle sixteenth chain sums the LAST segment a second time, from 16 more candidates on either side of the grid
+  // (grid indices -8..-1 and 16..23): sOut then has 32 entries, index = grid index + 8.
+  template <bool KEEP = false, bool WIDE = false>
+  __device__ __forceinline__ void candidates(uint32_t prods_addr, int (*sJ)[16], double *sX1, const double *sA, double *sOut, int group,
+                                             bool walker, int lane, Op32 *ops = nullptr) {
+    const int jA = lane & 15, kA = lane >> 4;          // A-operand lane: chain jA, term 4s+kA of its segment at step s
+    const int segA = 4 * (jA & 3) + (jA >> 2);         // ... and the segment that chain carries
+    sD = lane >> 2; col = lane & 3;
+    paddr = prods_addr + (uint32_t)((WIDE && segA == NSEG ? NB : segA) * SEGP + kA) * 8u;
+    walk_its = 0;
     const double A = sD < NSEG ? sA[sD] : 0.;
     // inclusive prefix over the segments, any order (only a guess): quads of a row, then rows
     double incl = A;
@@ -257,59 +305,71 @@ __device__ __forceinline__ double spec_exact_sum(uint32_t prods_addr, int (*sJ)[
     nU = ulp_pow2(incl, &nIU);
     nB = incl - 8. * nU;
     const int m16 = 4 * group + col;
-    const double stv = gBase + (double)m16 * gU;
+    int gi = m16;  // grid index of this lane's candidate
+    if constexpr (WIDE) {
+      const double gBq = row_shr<4>(gBase), gUq = row_shr<4>(gU);  // the quad before (all lanes shift: a DPP source lane must be active)
+      if (sD == NSEG) { gBase = gBq; gU = gUq; gi = m16 < 8 ? m16 - 8 : m16 + 8; }  // the last boundary's grid
+    }
+    const double stv = gBase + (double)gi * gU;
     if (walker) {
       // the walk's conversion of an off-grid offset from boundary l's ulps to boundary l + 1's, as three numbers per boundary:
-      // ((hi << ksp) + krn) >> ksn, to nearest (a guess only); lane 4*l holds those of the step from boundary l
+      // ((hi << ksp) + krn) >> ksn, to nearest (a guess only)
       const int ex = (__double2hiint(gU) >> 20) & 0x7ff, exn = (__double2hiint(nU) >> 20) & 0x7ff;  // exponent fields of the ulps (0: no grid)
       int ks = (ex && exn) ? ex - exn : 0;
       ks = ks > 31 ? 31 : (ks < -31 ? -31 : ks);
       ksp = max(ks, 0); ksn = max(-ks, 0); krn = ksn ? 1 << (ksn - 1) : 0;
     }
-    const double o = mfma_pass32(paddr, stv);
+    double o;
+    if constexpr (KEEP) o = mfma_pass32_keep(paddr, stv, *ops); else o = mfma_pass32(paddr, stv);
     if (sD < NSEG) sJ[sD][m16] = (sD < NB) ? (int)((o - nB) * nIU) : 0;
     if (sD == 0 && m16 == 0) *sX1 = o;  // segment 0 summed from +0: x_1, exact
+    if (sOut && (sD == NB || (WIDE && sD == NSEG))) sOut[WIDE ? gi + 8 : m16] = o;
   }
-  SPX_TICK(0)
-  __syncthreads();
-  SPX_TICK(1)
-  double res = 0.;
-  if (walker) {
-    // the 15 x 16 table in four registers: boundary l's row in lanes 16 * (l & 3) + m of tb[l >> 2]
+
+  // walk d_{l+1} = step_l(d_l) for l >= sp, one boundary after the other on the scalar unit: the offset lives in an SGPR, a table
+  // look-up is a v_readlane with a computed lane (no LDS round trip, no cross-lane work) and the result goes to lanes 4*(l+1) (as
+  // that segment's input) and 4*l (as this segment's expected output) by v_writelane. Branches are what costs here (~25 cycles
+  // each, taken or not), so the first walk (FIRST: sp == 1) has no start tests. Returns the offset at the last boundary.
+  template <bool FIRST>
+  __device__ __forceinline__ int walk() {
+    int ds = sd;
+    auto step = [&](auto lc) {
+      constexpr int l = decltype(lc)::value;
+      const int mm = ds & 15, hi = ds - mm;
+      int t = __builtin_amdgcn_readlane(l < 4 ? tb0 : l < 8 ? tb1 : l < 12 ? tb2 : tb3, 16 * (l & 3) + mm);
+      if (hi) t += ((hi << __builtin_amdgcn_readlane(ksp, 4 * l)) + __builtin_amdgcn_readlane(krn, 4 * l)) >> __builtin_amdgcn_readlane(ksn, 4 * l);
+      ds = __builtin_amdgcn_readfirstlane(t);
+      asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(dS) : "s"(ds), "i"(4 * (l + 1)));
+      asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(dE) : "s"(ds), "i"(4 * l));
+      walk_its++;
+    };
+    if (FIRST) static_for<1, NB>(step);
+    else static_for<1, NB>([&](auto lc) { if (decltype(lc)::value >= sp) step(lc); });
+    return ds;
+  }
+
+  // the walker, after the barrier behind candidates(): table into registers, first walk
+  __device__ __forceinline__ int first_walk(int (*sJ)[16], const double *sX1, int lane) {
     const int *sJf = &sJ[0][0];
-    const int tb0 = sJf[lane], tb1 = sJf[64 + lane], tb2 = sJf[128 + lane], tb3 = sJf[192 + lane];
+    tb0 = sJf[lane]; tb1 = sJf[64 + lane]; tb2 = sJf[128 + lane]; tb3 = sJf[192 + lane];
     const double x1 = *sX1;
-    // lane 4*s: xs = x_s, the input of segment s, xn = x_{s+1}, the output it must produce; x_0 = +0 and x_1 are exact
-    double xs = sD == 1 ? x1 : 0., xn = sD == 0 ? x1 : 0.;
-    int dS = 8, dE = 8;                              // lane 4*s: offsets of x_s / x_{s+1} on their candidate grids
-    int sp = 1;                                      // boundaries <= sp are exact
-    int sd = __builtin_amdgcn_readlane(tb0, 0);      // offset of x_sp on boundary sp's grid
-    SPX_TICK(2)
+    xs = sD == 1 ? x1 : 0.; xn = sD == 0 ? x1 : 0.;  // x_0 = +0 and x_1 are exact
+    dS = 8; dE = 8;
+    sp = 1;
+    sd = __builtin_amdgcn_readlane(tb0, 0);
+    return walk<true>();
+  }
+
+  // P2 until it holds: the exact sum, in every lane of the walker
+  template <bool KEEP = false>
+  __device__ __forceinline__ double verify(int dbg, long long &rounds, int lane, int *hist = nullptr, const Op32 *ops = nullptr) {
+    double res = 0.;
     for (int guard = 0; guard < 17; guard++) {
-      // ---- walk: d_{l+1} = step_l(d_l) for l >= sp, one boundary after the other on the scalar unit: the offset lives in an
-      // SGPR, a table look-up is a v_readlane with a computed lane (no LDS round trip, no cross-lane work) and the result
-      // goes to lanes 4*(l+1) (as that segment's input) and 4*l (as this segment's expected output) by v_writelane. Branches
-      // are what costs here (~25 cycles each, taken or not), so the first walk has no start tests.
-      int ds = sd;
-      auto step = [&](auto lc) {
-        constexpr int l = decltype(lc)::value;
-        const int mm = ds & 15, hi = ds - mm;
-        int t = __builtin_amdgcn_readlane(l < 4 ? tb0 : l < 8 ? tb1 : l < 12 ? tb2 : tb3, 16 * (l & 3) + mm);
-        if (hi) t += ((hi << __builtin_amdgcn_readlane(ksp, 4 * l)) + __builtin_amdgcn_readlane(krn, 4 * l)) >> __builtin_amdgcn_readlane(ksn, 4 * l);
-        ds = __builtin_amdgcn_readfirstlane(t);
-        asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(dS) : "s"(ds), "i"(4 * (l + 1)));
-        asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(dE) : "s"(ds), "i"(4 * l));
-        walk_its++;
-      };
-      if (guard == 0) static_for<1, NB>(step);
-      else static_for<1, NB>([&](auto lc) { if (decltype(lc)::value >= sp) step(lc); });
-      SPX_TICK(3)
+      if (guard > 0) walk<false>();
       if (sD > sp) xs = gBase + (double)dS * gU;
       if (sD >= sp) xn = nB + (double)dE * nU;
-      // ---- P2: verify every boundary (column 0 of every segment; the other columns sum from whatever they hold)
-      SPX_TICK(4)
-      res = mfma_pass32(paddr, xs);
-      SPX_TICK(5)
+      // every boundary at once (column 0 of every segment; the other columns sum from whatever they hold)
+      if constexpr (KEEP) res = mfma_pass32_regs(xs, *ops); else res = mfma_pass32(paddr, xs);
       const bool bad = (col == 0) && (sD < NB) && (__double_as_longlong(res) != __double_as_longlong(xn));
       const unsigned long long mask = __ballot(bad);
       rounds++;
@@ -338,8 +398,21 @@ __device__ __forceinline__ double spec_exact_sum(uint32_t prods_addr, int (*sJ)[
       sd = __builtin_amdgcn_readfirstlane((int)((xt - bq) * iq));
     }
     if (dbg & 1024) rounds += (long long)walk_its << 32;
-    res = bcast(res, 4 * NB);  // the last segment's output: the sum (to every lane of the walker)
-    SPX_TICK(6)
+    return bcast(res, 4 * NB);  // the last segment's output: the sum
+  }
+};
+
+template <int NSEG, int STEPS, int SEGP>
+__device__ __forceinline__ double spec_exact_sum(uint32_t prods_addr, int (*sJ)[16], double *sX1, const double *sA, int group,
+                                                 bool walker, int dbg, long long &rounds, const int lane, int *hist = nullptr) {
+  static_assert(STEPS == 32, "one pass = 32 MFMA steps");
+  SpecSum<NSEG, SEGP> ss;
+  if (group >= 0) ss.candidates(prods_addr, sJ, sX1, sA, nullptr, group, walker, lane);
+  __syncthreads();
+  double res = 0.;
+  if (walker) {
+    ss.first_walk(sJ, sX1, lane);
+    res = ss.verify(dbg, rounds, lane, hist);
   }
   return res;
 }
@@ -642,6 +715,9 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
 #ifndef L1_NT
 #define L1_NT 1024
 #endif
+#ifndef L1_EARLY
+#define L1_EARLY (L1_NT == 1024)
+#endif
 #define L1_R (2048 / L1_NT)
 #define L1_CH 256
 #define L1_RLO 2048
@@ -650,7 +726,13 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
 __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs, const uint16_t *__restrict__ gtab, int bits) {
   constexpr int S = 1280, T = 1920, NT = L1_NT, R = L1_R, CH = L1_CH, MO = L1_RLO - 1, MX = L1_RLX - 1;
   constexpr int SEG = L1_SEG, SEGP = L1_SEGP, NSEG = T / SEG;  // 15 segments of 128 products
+#if L1_EARLY
+  __shared__ double prods2[2][16 * SEGP];  // products of sample t in [t & 1]: the walker verifies t while the tap waves write t + 1
+  __shared__ double sOut[32], vexact;
+  __shared__ int specf, vok;
+#else
   __shared__ double prods[16 * SEGP];
+#endif
   __shared__ double sA[16];  // approximate segment sums (the guess of spec_exact_sum)
   __shared__ double ringo[L1_RLO];  // own channel's stage inputs   (taps 0..1279: lags 1..1280)
   __shared__ double ringx[L1_RLX];  // other channel's stage inputs (taps 1280..1919)
@@ -683,7 +765,11 @@ __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs
   for (int i = tid; i < (2 << bits); i += NT) tab[i] = gtab[i];
   for (int i = tid; i < L1_RLO; i += NT) ringo[i] = 0.;
   for (int i = tid; i < L1_RLX; i += NT) ringx[i] = 0.;
+#if L1_EARLY
+  for (int i = tid; i < 2 * 16 * SEGP; i += NT) (&prods2[0][0])[i] = 0.;  // chain 15 of the MFMA passes is idle: keep its operands finite
+#else
   for (int i = tid; i < 16 * SEGP; i += NT) prods[i] = 0.;  // chain 15 of the MFMA passes is idle: keep its operands finite
+#endif
   __syncthreads();
 
   double w[R], eg[R], mu[R];
@@ -722,12 +808,10 @@ __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs
   // that tail runs under the older waves' vector work (same-run A/B: 6.70k -> 6.62k cycles per sample)
   if (wave >= 12) __builtin_amdgcn_s_setprio(3); else if (wave >= 8) __builtin_amdgcn_s_setprio(2); else if (wave >= 4) __builtin_amdgcn_s_setprio(1);
 #ifdef L1_PROF  // phase clocks of every wave (tools/l1_phases.py): products | P1 | walk + verification | update, until its barrier
-  long long pf[4] = {0, 0, 0, 0}, pfT = clock64(), spxv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#define L1_SPX , spxv
+  long long pf[4] = {0, 0, 0, 0}, pfT = clock64();
 #define L1_TICK(i) { const long long now_ = clock64(); pf[i] += now_ - pfT; pfT = now_; }
 #else
 #define L1_TICK(i)
-#define L1_SPX
 #endif
 
   auto flush = [&](int tb, int te) {  // p and val[k+1] = x - p (CalcError, profile.cpp:141-148) for times [tb, te)
@@ -741,6 +825,132 @@ __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs
     }
   };
 
+#if L1_EARLY
+  // ---- Early prediction. Wave 15 owns no taps: it is candidate group 0, the walker and the verifier (waves 0..2 are the other
+  // candidate groups). When the walk ends on a candidate of the last boundary, the sum it predicts (sOut) is published at once
+  // and the tap waves update -- and multiply for the next sample -- with it while wave 15 runs the verification pass(es). The
+  // weights of before are kept for one sample; when the exact sum differs from the prediction (the walk was a guess: a few
+  // per cent of the samples) the update and the products are done again. A sample's result is only ever the verified sum.
+  static_assert(NT == 1024, "the walker is the wave without taps");
+  const int grp = wave == 15 ? 0 : (wave < 3 ? wave + 1 : -1);
+  const bool walker = wave == 15;
+  SpecSum<NSEG, SEGP> ss;
+  double h[R], wS[R], egS[R];
+  long long n_spec = 0, n_redo = 0;  // (L1_PROF statistics)
+  int pend = 0;  // the update of sample t - 1 used a prediction: its verification is due behind the next barrier
+  auto products = [&](int t) {  // w[i]*hist[i] (nlms.h:111) -> prods2[t & 1], approximate segment sum -> sA
+    double part = 0.;
+#pragma unroll
+    for (int r = 0; r < R; r++)  // all history reads first: behind a product store the compiler would not move them
+      h[r] = *(const __attribute__((address_space(3))) double *)(uintptr_t)(hb[r] + 8u * (uint32_t)((t + hoff[r]) & hmask[r]));
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      const double pr = w[r] * h[r];
+      if (valid[r]) prods2[t & 1][pa[r]] = pr;
+      part = r ? part + pr : pr;
+    }
+    part = row_prefix16(part);  // tree order: a guess only
+    int lo = __double2loint(part), hi = __double2hiint(part);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1 and 3
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x142, 0xA, 0xF, false);
+    part += __hiloint2double(hi, lo);
+    lo = __double2loint(part); hi = __double2hiint(part);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2 and 3
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x143, 0xC, 0xF, false);
+    part += __hiloint2double(hi, lo);
+    if (hl == HW - 1 && valid[0]) sA[seg] = part;
+  };
+  auto update = [&](int t, double pred, const double (&hh)[R]) {  // nlms.h:114-129
+    const double err = ringo[t & MO] - pred;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      if (valid[r] && !(dbg & 2)) {
+        const double grad = err * hh[r];
+        eg[r] = 0.95 * eg[r] + (1.0 - 0.95) * (grad * grad);
+        w[r] += (mu[r] * grad * rsq_emul2(eg[r] + 0.001, tab, bits));
+      }
+    }
+  };
+  auto settle = [&](int t, bool again) {  // behind a barrier: was the prediction used for sample t - 1 the exact sum?
+    if (pend && !vok) {  // no (uniform): update t - 1 again from the kept weights, with the exact sum
+      n_redo++;
+      double hold[R];
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        hold[r] = *(const __attribute__((address_space(3))) double *)(uintptr_t)(hb[r] + 8u * (uint32_t)((t - 1 + hoff[r]) & hmask[r]));
+        w[r] = wS[r]; eg[r] = egS[r];
+      }
+      update(t - 1, vexact, hold);
+      if (again) { products(t); __syncthreads(); }
+    }
+    pend = 0;
+  };
+  // Two loops with the same sequence of barriers: the walker's (no taps; the 32 MFMA operands of each of its lanes stay in
+  // registers from the candidate pass, so that its verification needs no LDS access while the tap waves are busy in the LDS)
+  // and the tap waves'.
+  if (walker) {
+    Op32 ops;
+    for (int t = t0; t < tend; t++) {
+      if ((t & (CH - 1)) == 0) __syncthreads();  // (refill)
+      L1_TICK(0)
+      __syncthreads();
+      if (pend && !vok) { n_redo++; __syncthreads(); }
+      ss.template candidates<true, true>((uint32_t)(uintptr_t)&prods2[t & 1][0], sJ, &sX1, sA, sOut, 0, true, lane, &ops);
+      __syncthreads();
+      double pv = 0.;
+      const int dl = ss.first_walk(sJ, &sX1, lane);
+      int sf = 0;
+      if ((unsigned)(dl + 8) < 32u) {  // (32 candidates at the last boundary: SpecSum::candidates<.., WIDE>)
+        pv = sOut[dl + 8];
+        sf = 1;
+        if (lane == 0) { predv = pv; specf = 1; }
+      } else {  // the walk left the candidates at the last boundary: nothing to predict with
+        const double ex = ss.template verify<true>(dbg, rounds, lane, hist, &ops);
+        if (lane == 0) { predv = ex; specf = 0; pbuf[t & (CH - 1)] = ex; }
+      }
+      L1_TICK(1)
+      __syncthreads();
+      L1_TICK(2)
+      if (sf) {
+        const double ex = ss.template verify<true>(dbg, rounds, lane, hist, &ops);
+        if (lane == 0) { vok = __double_as_longlong(ex) == __double_as_longlong(pv); vexact = ex; pbuf[t & (CH - 1)] = ex; }
+      }
+      pend = sf;
+      n_spec += sf;
+      L1_TICK(3)
+    }
+    __syncthreads();
+  } else {
+    for (int t = t0; t < tend; t++) {
+      if ((t & (CH - 1)) == 0) {
+        for (int k = tid; k < CH; k += NT) {
+          const int tau = t + k;
+          ringo[tau & MO] = (tau < tend) ? xo_in[tau] : 0.;
+          ringx[tau & MX] = (tau < tend) ? xx_in[tau] : 0.;
+        }
+        __syncthreads();
+      }
+      products(t);
+      L1_TICK(0)
+      __syncthreads();
+      settle(t, true);
+      if ((t & (CH - 1)) == 0 && t > t0) flush(t - CH, t);  // (behind the barrier: the last prediction of the block is the verifier's)
+      if (grp > 0) ss.template candidates<false, true>((uint32_t)(uintptr_t)&prods2[t & 1][0], sJ, &sX1, sA, sOut, grp, false, lane);
+      __syncthreads();
+      L1_TICK(1)
+      __syncthreads();
+      L1_TICK(2)
+      const int sf = specf;
+#pragma unroll
+      for (int r = 0; r < R; r++) { wS[r] = w[r]; egS[r] = eg[r]; }
+      update(t, predv, h);
+      pend = sf;
+      L1_TICK(3)
+    }
+    __syncthreads();
+    settle(tend, false);
+  }
+#else
   for (int t = t0; t < tend; t++) {
     if ((t & (CH - 1)) == 0) {
       if (t > t0) flush(t - CH, t);
@@ -784,7 +994,7 @@ __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs
     L1_TICK(0)
     __syncthreads();
     // ---- pred = 0.; for i: pred += w[i]*hist[i]  -- strict order (spec_exact_sum: waves 0..3 sum candidates, wave 0 verifies)
-    const double res = spec_exact_sum<NSEG, SEG / 4, SEGP>((uint32_t)(uintptr_t)&prods[0], sJ, &sX1, sA, wave < 4 ? wave : -1, wave == 0, dbg, rounds, lane, hist L1_SPX);
+    const double res = spec_exact_sum<NSEG, SEG / 4, SEGP>((uint32_t)(uintptr_t)&prods[0], sJ, &sX1, sA, wave < 4 ? wave : -1, wave == 0, dbg, rounds, lane, hist);
     if (wave == 0 && lane == SPEC_RESULT_LANE(NSEG)) {
       predv = res;
       pbuf[t & (CH - 1)] = res;
@@ -804,14 +1014,18 @@ __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs
     }
     L1_TICK(3)
   }
+#endif
   if (tend > t0) flush((tend - 1) & ~(CH - 1), tend);
 #ifdef L1_PROF
   __syncthreads();
-  if (lane == 0 && tend - t0 >= 128) { for (int i = 0; i < 4; i++) pout[t0 + 4 * wave + i] = (double)pf[i]; if (wave == 0) for (int i = 0; i < 8; i++) pout[t0 + 64 + i] = (double)spxv[i]; }
+  if (lane == 0 && tend - t0 >= 128) { for (int i = 0; i < 4; i++) pout[t0 + 4 * wave + i] = (double)pf[i]; }
+#if L1_EARLY
+  if (tid == 960 && tend - t0 >= 128) { pout[t0 + 64] = (double)n_spec; pout[t0 + 65] = (double)n_redo; pout[t0 + 67] = (double)rounds; }
+#endif
 #endif
   if (dbg & 128) {  // DEBUG: number of P2 passes
     __syncthreads();
-    if (tid == 0) pout[t0] = (double)rounds;
+    if (tid == (L1_EARLY ? 960 : 0)) pout[t0] = (double)rounds;
   }
 #ifdef SACOPT_ABLATE
   if (dbg & 2048) {  // DEBUG: histogram of the largest distance (in ulps) between guess and exact value over the boundaries of a sample

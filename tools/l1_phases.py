@@ -20,8 +20,6 @@ print("wave: products | to-barrier-after-sum | wait | update   (cycles per sampl
 for w in range(16):
     print(w, list(ph[w]))
 
-sp = (q0[64:72] / n).round().astype(int)
-print('wave 0 inside spec_exact_sum: guess + P1 pass + table store', sp[0], '| barrier', sp[1], '| table load', sp[2], '| walk', sp[3],
-      '| start values + shuffles', sp[4], '| verification pass', sp[5], '| compare, rounds > 1', sp[6])
 
+print('early prediction: samples updated with the prediction', q0[64] / n, ' redone', q0[65] / n, ' verification passes per sample', q0[67] / n)
 ctx.close()
