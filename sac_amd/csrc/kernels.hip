@@ -140,6 +140,69 @@ __device__ __forceinline__ double mfma_pass32(uint32_t addr, double acc) {
 }
 #undef MF
 
+#define MF(areg) "v_mfma_f64_4x4x4_4b_f64 %0, " areg ", %2, %0\n s_nop 3\n"
+// 56 steps (224 terms), straight-line (generated: 8 steps per group, the next group's operands always in flight)
+__device__ __forceinline__ double mfma_chain56(uint32_t addr, double acc = 0.) {
+  double one = 1.0;
+  double a0, a1, a2, a3, a4, a5, a6, a7, b0, b1, b2, b3, b4, b5, b6, b7;
+  asm volatile(
+      "ds_read_b64 %3, %1 offset:0\n ds_read_b64 %4, %1 offset:32\n ds_read_b64 %5, %1 offset:64\n ds_read_b64 %6, %1 offset:96\n ds_read_b64 %7, %1 offset:128\n ds_read_b64 %8, %1 offset:160\n ds_read_b64 %9, %1 offset:192\n ds_read_b64 %10, %1 offset:224\n"
+      "ds_read_b64 %11, %1 offset:256\n ds_read_b64 %12, %1 offset:288\n ds_read_b64 %13, %1 offset:320\n ds_read_b64 %14, %1 offset:352\n ds_read_b64 %15, %1 offset:384\n ds_read_b64 %16, %1 offset:416\n ds_read_b64 %17, %1 offset:448\n ds_read_b64 %18, %1 offset:480\n"
+      "s_waitcnt lgkmcnt(8)\n s_nop 1\n"
+      MF("%3") MF("%4") MF("%5") MF("%6") MF("%7") MF("%8") MF("%9") MF("%10")
+      "ds_read_b64 %3, %1 offset:512\n ds_read_b64 %4, %1 offset:544\n ds_read_b64 %5, %1 offset:576\n ds_read_b64 %6, %1 offset:608\n ds_read_b64 %7, %1 offset:640\n ds_read_b64 %8, %1 offset:672\n ds_read_b64 %9, %1 offset:704\n ds_read_b64 %10, %1 offset:736\n"
+      "s_waitcnt lgkmcnt(8)\n s_nop 1\n"
+      MF("%11") MF("%12") MF("%13") MF("%14") MF("%15") MF("%16") MF("%17") MF("%18")
+      "ds_read_b64 %11, %1 offset:768\n ds_read_b64 %12, %1 offset:800\n ds_read_b64 %13, %1 offset:832\n ds_read_b64 %14, %1 offset:864\n ds_read_b64 %15, %1 offset:896\n ds_read_b64 %16, %1 offset:928\n ds_read_b64 %17, %1 offset:960\n ds_read_b64 %18, %1 offset:992\n"
+      "s_waitcnt lgkmcnt(8)\n s_nop 1\n"
+      MF("%3") MF("%4") MF("%5") MF("%6") MF("%7") MF("%8") MF("%9") MF("%10")
+      "ds_read_b64 %3, %1 offset:1024\n ds_read_b64 %4, %1 offset:1056\n ds_read_b64 %5, %1 offset:1088\n ds_read_b64 %6, %1 offset:1120\n ds_read_b64 %7, %1 offset:1152\n ds_read_b64 %8, %1 offset:1184\n ds_read_b64 %9, %1 offset:1216\n ds_read_b64 %10, %1 offset:1248\n"
+      "s_waitcnt lgkmcnt(8)\n s_nop 1\n"
+      MF("%11") MF("%12") MF("%13") MF("%14") MF("%15") MF("%16") MF("%17") MF("%18")
+      "ds_read_b64 %11, %1 offset:1280\n ds_read_b64 %12, %1 offset:1312\n ds_read_b64 %13, %1 offset:1344\n ds_read_b64 %14, %1 offset:1376\n ds_read_b64 %15, %1 offset:1408\n ds_read_b64 %16, %1 offset:1440\n ds_read_b64 %17, %1 offset:1472\n ds_read_b64 %18, %1 offset:1504\n"
+      "s_waitcnt lgkmcnt(8)\n s_nop 1\n"
+      MF("%3") MF("%4") MF("%5") MF("%6") MF("%7") MF("%8") MF("%9") MF("%10")
+      "ds_read_b64 %3, %1 offset:1536\n ds_read_b64 %4, %1 offset:1568\n ds_read_b64 %5, %1 offset:1600\n ds_read_b64 %6, %1 offset:1632\n ds_read_b64 %7, %1 offset:1664\n ds_read_b64 %8, %1 offset:1696\n ds_read_b64 %9, %1 offset:1728\n ds_read_b64 %10, %1 offset:1760\n"
+      "s_waitcnt lgkmcnt(8)\n s_nop 1\n"
+      MF("%11") MF("%12") MF("%13") MF("%14") MF("%15") MF("%16") MF("%17") MF("%18")
+      "s_waitcnt lgkmcnt(0)\n s_nop 1\n"
+      MF("%3") MF("%4") MF("%5") MF("%6") MF("%7") MF("%8") MF("%9") MF("%10")
+      "s_nop 7\n"
+      : "+v"(acc), "+v"(addr), "+v"(one), "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(a4), "=&v"(a5), "=&v"(a6),
+        "=&v"(a7), "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3), "=&v"(b4), "=&v"(b5), "=&v"(b6), "=&v"(b7)
+      :
+      : "memory");
+  return acc;
+}
+// 40 steps (160 terms), straight-line (generated: 8 steps per group, the next group's operands always in flight)
+__device__ __forceinline__ double mfma_chain40(uint32_t addr, double acc = 0.) {
+  double one = 1.0;
+  double a0, a1, a2, a3, a4, a5, a6, a7, b0, b1, b2, b3, b4, b5, b6, b7;
+  asm volatile(
+      "ds_read_b64 %3, %1 offset:0\n ds_read_b64 %4, %1 offset:32\n ds_read_b64 %5, %1 offset:64\n ds_read_b64 %6, %1 offset:96\n ds_read_b64 %7, %1 offset:128\n ds_read_b64 %8, %1 offset:160\n ds_read_b64 %9, %1 offset:192\n ds_read_b64 %10, %1 offset:224\n"
+      "ds_read_b64 %11, %1 offset:256\n ds_read_b64 %12, %1 offset:288\n ds_read_b64 %13, %1 offset:320\n ds_read_b64 %14, %1 offset:352\n ds_read_b64 %15, %1 offset:384\n ds_read_b64 %16, %1 offset:416\n ds_read_b64 %17, %1 offset:448\n ds_read_b64 %18, %1 offset:480\n"
+      "s_waitcnt lgkmcnt(8)\n s_nop 1\n"
+      MF("%3") MF("%4") MF("%5") MF("%6") MF("%7") MF("%8") MF("%9") MF("%10")
+      "ds_read_b64 %3, %1 offset:512\n ds_read_b64 %4, %1 offset:544\n ds_read_b64 %5, %1 offset:576\n ds_read_b64 %6, %1 offset:608\n ds_read_b64 %7, %1 offset:640\n ds_read_b64 %8, %1 offset:672\n ds_read_b64 %9, %1 offset:704\n ds_read_b64 %10, %1 offset:736\n"
+      "s_waitcnt lgkmcnt(8)\n s_nop 1\n"
+      MF("%11") MF("%12") MF("%13") MF("%14") MF("%15") MF("%16") MF("%17") MF("%18")
+      "ds_read_b64 %11, %1 offset:768\n ds_read_b64 %12, %1 offset:800\n ds_read_b64 %13, %1 offset:832\n ds_read_b64 %14, %1 offset:864\n ds_read_b64 %15, %1 offset:896\n ds_read_b64 %16, %1 offset:928\n ds_read_b64 %17, %1 offset:960\n ds_read_b64 %18, %1 offset:992\n"
+      "s_waitcnt lgkmcnt(8)\n s_nop 1\n"
+      MF("%3") MF("%4") MF("%5") MF("%6") MF("%7") MF("%8") MF("%9") MF("%10")
+      "ds_read_b64 %3, %1 offset:1024\n ds_read_b64 %4, %1 offset:1056\n ds_read_b64 %5, %1 offset:1088\n ds_read_b64 %6, %1 offset:1120\n ds_read_b64 %7, %1 offset:1152\n ds_read_b64 %8, %1 offset:1184\n ds_read_b64 %9, %1 offset:1216\n ds_read_b64 %10, %1 offset:1248\n"
+      "s_waitcnt lgkmcnt(8)\n s_nop 1\n"
+      MF("%11") MF("%12") MF("%13") MF("%14") MF("%15") MF("%16") MF("%17") MF("%18")
+      "s_waitcnt lgkmcnt(0)\n s_nop 1\n"
+      MF("%3") MF("%4") MF("%5") MF("%6") MF("%7") MF("%8") MF("%9") MF("%10")
+      "s_nop 7\n"
+      : "+v"(acc), "+v"(addr), "+v"(one), "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(a4), "=&v"(a5), "=&v"(a6),
+        "=&v"(a7), "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3), "=&v"(b4), "=&v"(b5), "=&v"(b6), "=&v"(b7)
+      :
+      : "memory");
+  return acc;
+}
+#undef MF
+
 // mfma_pass32 that KEEPS the 32 operands of every lane (64 VGPRs), and the same pass from kept operands: no LDS access at all.
 // For a wave that sums the same products twice (k_lms1c's walker: candidate pass, then verification while the other waves
 // are busy in the LDS).
@@ -427,6 +490,10 @@ __device__ __forceinline__ double spec_exact_sum(uint32_t prods_addr, int (*sJ)[
 // ------------------------------------------------------------------------------------------
 #define L1_SEG 128   // products per segment (32 MFMA steps)
 #define L1_SEGP 130  // segment stride in LDS: the 16 chain lanes of a ds_read_b64 half on 16 different 4-bank groups
+#ifndef H_SPLIT
+#define H_SPLIT 224  // (256,128) stage: terms summed from +0 by wave 0 (56 MFMA steps); the candidate waves guess that sum first, so they get the shorter rest (40 steps)
+#endif
+static_assert(H_SPLIT == 192 || H_SPLIT == 224, "chains exist for 192 + 192 and 224 + 160 terms");
 #ifndef LMS_HALVES_WAVES
 #define LMS_HALVES_WAVES 2  // candidate waves of the (256,128) stage's second half: 32 candidates per channel each
 #endif
@@ -460,7 +527,7 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
   // output is the exact left-to-right sum of all 384 terms; if not, wave 0 sums the second half from the exact value
   // (48 more steps, as long as the undivided chain). Exactness never rests on the guess.
   constexpr bool HALVES = !SPEC && T == 384;
-  __shared__ double hX1[2], hStart[2][64], hOut[2][64], hGb[2], hIu[2], hP2[2];
+  __shared__ double hX1[2], hOut[2][64], hGb[2], hIu[2], hU[2], hP2[2];
 
   const LmsJob job = jobs[blockIdx.x];
   const int tid = threadIdx.x, t0 = job.t0, tend = job.t0 + job.n;
@@ -539,6 +606,12 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
     }
   };
   long long hmiss = 0;
+#ifdef H_PROF  // phase clocks of every wave of the (256,128) stage (tools/h_phases.py): products | sums until the barrier | look-up (+ second pass) | update
+  long long hp[4] = {0, 0, 0, 0}, hpT = clock64();
+#define H_TICK(i) { if (HALVES) { const long long now_ = clock64(); hp[i] += now_ - hpT; hpT = now_; } }
+#else
+#define H_TICK(i)
+#endif
   for (int t = t0; t < tend; t++) {
     if ((t & (CH - 1)) == 0) {
       if (HALVES) __syncthreads();  // the last prediction went to pbuf after the sample's last barrier
@@ -572,6 +645,7 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
         if (hl == 31 && valid[0]) sA[BOTH ? c : hch][hseg] = v;
       }
     }
+    H_TICK(0)
     __syncthreads();
     // ---- pred = 0.; for i: pred += w[i]*hist[i]  -- strict order, on the matrix pipe
     if constexpr (SPEC) {
@@ -586,13 +660,14 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
         pbuf[sc][t & (CH - 1)] = res;
       }
     } else if constexpr (HALVES) {
-      constexpr int H = T / 2;  // 192 terms = 48 steps
+      constexpr int H = H_SPLIT;  // terms of the first part (wave 0, from +0); the candidate waves sum the rest after guessing its sum
       if (wave == 0) {
-        const double acc = mfma_chain_lds<3>((uint32_t)(uintptr_t)mp);
+        const double acc = H == 192 ? mfma_chain_lds<3>((uint32_t)(uintptr_t)mp) : mfma_chain56((uint32_t)(uintptr_t)mp);
         if (lane == 0 || lane == 16) hX1[lane >> 4] = acc;
       } else if (wave >= 1 && wave <= LMS_HALVES_WAVES) {  // 32 candidates per channel each: offsets -32..-1 and 0..31 ulps from the guess
         double g0 = (prods[0][lane] + prods[0][64 + lane]) + prods[0][128 + lane];  // any order: only a guess
         double g1 = (prods[1][lane] + prods[1][64 + lane]) + prods[1][128 + lane];
+        if (H > 192 && lane < H - 192) { g0 += prods[0][192 + lane]; g1 += prods[1][192 + lane]; }
         {  // wave sums by DPP: 16-lane rows, then row 0 -> 1 and 2 -> 3, then rows 0..1 -> 2..3: lane 63 has the total
           double gg[2] = {g0, g1};
 #pragma unroll
@@ -616,32 +691,33 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
         double iu;
         const double u = ulp_pow2(g, &iu);
         const double stv = (g - 16. * LMS_HALVES_WAVES * u) + (double)m * u;
-        const double out = mfma_chain_lds<3>((uint32_t)(uintptr_t)(mp + H), stv);
-        hStart[chD][m] = stv;
+        const double out = H == 192 ? mfma_chain_lds<3>((uint32_t)(uintptr_t)(mp + H), stv) : mfma_chain40((uint32_t)(uintptr_t)(mp + H), stv);
         hOut[chD][m] = out;
-        if (m == 0) { hGb[chD] = stv; hIu[chD] = iu; }
+        if (m == 0) { hGb[chD] = stv; hIu[chD] = iu; hU[chD] = u; }
       }
+      H_TICK(1)
       __syncthreads();
       double pr[2];
       bool miss = false;
 #pragma unroll
-      for (int c = 0; c < 2; c++) {
-        const double x1 = hX1[c];
-        int mi = (int)((x1 - hGb[c]) * hIu[c]);
+      for (int c = 0; c < 2; c++) {  // which candidate is the exact first part? (its start value recomputed as its wave computed it)
+        const double x1 = hX1[c], gb = hGb[c];
+        int mi = (int)((x1 - gb) * hIu[c]);
         mi = mi < 0 ? 0 : (mi > 32 * LMS_HALVES_WAVES - 1 ? 32 * LMS_HALVES_WAVES - 1 : mi);
-        if (__double_as_longlong(hStart[c][mi]) == __double_as_longlong(x1)) pr[c] = hOut[c][mi];
+        if (__double_as_longlong(gb + (double)mi * hU[c]) == __double_as_longlong(x1)) pr[c] = hOut[c][mi];
         else miss = true;
       }
       if (miss) {  // uniform: every thread read the same values
         hmiss++;
         if (wave == 0) {
-          const double acc = mfma_chain_lds<3>((uint32_t)(uintptr_t)(mp + H), hX1[(lane >> 4) & 1]);
+          const double acc = H == 192 ? mfma_chain_lds<3>((uint32_t)(uintptr_t)(mp + H), hX1[(lane >> 4) & 1]) : mfma_chain40((uint32_t)(uintptr_t)(mp + H), hX1[(lane >> 4) & 1]);
           if (lane == 0 || lane == 16) hP2[lane >> 4] = acc;
         }
         __syncthreads();
         pr[0] = hP2[0]; pr[1] = hP2[1];
       }
       if (tid < 2) pbuf[tid][t & (CH - 1)] = tid ? pr[1] : pr[0];
+      H_TICK(2)
       // ---- Update (nlms.h:114-129)
       const double e0 = ring[0][t & M] - pr[0];
       const double e1 = ring[1][t & M] - pr[1];
@@ -654,6 +730,7 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
           w[r] += (mu[r] * grad * rsq_emul2(eg[r] + 0.001, tab, bits));
         }
       }
+      H_TICK(3)
       continue;
     } else
     if (wave == 0) {
@@ -690,6 +767,9 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
   }
   if (HALVES) __syncthreads();
   if (tend > t0) flush((tend - 1) & ~(CH - 1), tend);
+#ifdef H_PROF
+  if (HALVES) { __syncthreads(); if (lane == 0 && tend - t0 >= 64) for (int i = 0; i < 4; i++) job.p[0][t0 + 4 * wave + i] = (double)hp[i]; }
+#endif
   if (HALVES && (dbg & 128)) {  // DEBUG: samples whose first half missed the candidates
     __syncthreads();
     if (tid == 0) job.p[0][t0] = (double)hmiss;
@@ -1795,9 +1875,14 @@ __global__ __launch_bounds__(256) void k_sumkat(const double *__restrict__ x, do
 // ------------------------------------------------------------------------------------------
 // host-callable launchers (sacopt.cpp is compiled by the host compiler pass of the same TU set)
 // ------------------------------------------------------------------------------------------
+// the (256,128) stage: threads x taps per thread (768 tap slots of both channels)
+#ifndef H2_NT
+#define H2_NT 256
+#define H2_R 3
+#endif
 extern "C" int sacopt_lms_state_doubles(int S, int D) {  // 2 * R * NT of the matching k_lms instance
   if (S == 1280 && D == 640) return 2 * 4 * 1024;
-  if (S == 256 && D == 128) return 2 * 3 * 256;
+  if (S == 256 && D == 128) return 2 * H2_R * H2_NT;
   if (S == 32 && D == 16) return 2 * 2 * 64;
   if (S == 8 && D == 4) return 2 * 1 * 64;
   return 0;
@@ -1835,7 +1920,7 @@ extern "C" int sacopt_launch_lms(int S, int D, const LmsJob *jobs, int njobs, co
     else if (S == 8 && D == 4) hipLaunchKernelGGL((k_lms<8, 4, 64, 1, 1024, false>), dim3(njobs), dim3(64), 0, st, jobs, tab, bits);
     else return 1;
   }
-  else if (S == 256 && D == 128) hipLaunchKernelGGL((k_lms<256, 128, 256, 3, 512, false, 128>), dim3(njobs), dim3(256), 0, st, jobs, tab, bits);
+  else if (S == 256 && D == 128) hipLaunchKernelGGL((k_lms<256, 128, H2_NT, H2_R, 512, false, 128>), dim3(njobs), dim3(H2_NT), 0, st, jobs, tab, bits);
   else if (S == 32 && D == 16) hipLaunchKernelGGL((k_lms<32, 16, 64, 2, 256, false, 128>), dim3(njobs), dim3(64), 0, st, jobs, tab, bits);
   else if (S == 8 && D == 4) hipLaunchKernelGGL((k_lms<8, 4, 64, 1, 256, false, 128>), dim3(njobs), dim3(64), 0, st, jobs, tab, bits);
   else return 1;
