@@ -1897,15 +1897,15 @@ extern "C" int sacopt_lms_state_doubles(int S, int D) {  // 2 * R * NT of the ma
 #else
 #define ABL_SW(bits) 0
 #endif
-extern "C" int sacopt_lms_variant(int S, int D, int njobs, int bits) {
+extern "C" int sacopt_lms_variant(int S, int D, int njobs, int bits, int limit) {  // limit: most chains that still get two CUs each
   if (S != 1280 || D != 640) return 0;
-  return (!(ABL_SW(bits) & (8 | 256)) && (njobs <= 20 || (ABL_SW(bits) & 512))) ? 1 : 0;
+  return (!(ABL_SW(bits) & (8 | 256)) && (njobs <= limit || (ABL_SW(bits) & 512))) ? 1 : 0;
 }
 extern "C" int sacopt_launch_lms(int S, int D, const LmsJob *jobs, int njobs, const uint16_t *tab, int bits,
-                                 hipStream_t st) {
+                                 hipStream_t st, int limit) {
   if (njobs <= 0) return 0;
   if (S == 1280 && D == 640) {
-    if (sacopt_lms_variant(S, D, njobs, bits)) hipLaunchKernelGGL(k_lms1c, dim3(2 * njobs), dim3(L1_NT), 0, st, jobs, tab, bits);
+    if (sacopt_lms_variant(S, D, njobs, bits, limit)) hipLaunchKernelGGL(k_lms1c, dim3(2 * njobs), dim3(L1_NT), 0, st, jobs, tab, bits);
     else if (ABL_SW(bits) & 8) hipLaunchKernelGGL((k_lms<1280, 640, 1024, 4, 2048, false>), dim3(njobs), dim3(1024), 0, st, jobs, tab, bits);
     // 1024 threads are faster for a chain alone (9.4k against 10.0k cycles per sample) but slower in the optimizer's
     // rounds, where the follower stages want room on the same CUs (optimize 571 against 526 ms): A/B switch only

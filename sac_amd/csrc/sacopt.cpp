@@ -22,8 +22,13 @@
 
 extern "C" {
 int sacopt_lms_state_doubles(int S, int D);
-int sacopt_launch_lms(int S, int D, const LmsJob *jobs, int njobs, const uint16_t *tab, int bits, hipStream_t st);
-int sacopt_lms_variant(int S, int D, int njobs, int bits);
+int sacopt_launch_lms(int S, int D, const LmsJob *jobs, int njobs, const uint16_t *tab, int bits, hipStream_t st, int limit);
+int sacopt_lms_variant(int S, int D, int njobs, int bits, int limit);
+// (1280,640) stage: k_lms1c gives a chain two CUs (4.98k cycles per sample against ~8.3k for both channels on one CU): taken
+// for up to 20 chains per launch. Beyond that a call is throughput-bound and the two-channel kernel is cheaper per CU. (A window
+// evaluation with up to 96 chains on k_lms1c changed nothing for encode calls of 2..15 frames: the full-frame pass bounds them.)
+#define L1C_FRAMES 20
+#define L1C_WINDOW 20
 int sacopt_launch_lpc3(const LpcJob *jobs, int njobs, int max_n, int ols_n, hipStream_t st);
 int sacopt_launch_lpc2(const LpcJob *jobs, int njobs, int max_n, hipStream_t st);
 int sacopt_launch_mix(int ns, const MixJob *jobs, int njobs, hipStream_t st);
@@ -765,14 +770,14 @@ static int eval_chains(sacopt_ctx *c, const ProfDesc &pd, const std::vector<DevF
         if (s <= pd.nlms) {
           const StageDesc &sd = pd.lms[s - 1];
           // the dominant kernel (k_lms1c for the high profile, the first LMS stage otherwise) is timed for the roofline
-          const bool dominant = (s == 1) && (sd.S != 1280 || sacopt_lms_variant(sd.S, sd.D, n_jobs[s], c->bits) == c->timed_variant);
+          const bool dominant = (s == 1) && (sd.S != 1280 || sacopt_lms_variant(sd.S, sd.D, n_jobs[s], c->bits, L1C_WINDOW) == c->timed_variant);
           hipEvent_t a = nullptr, b = nullptr;
           if (dominant) {
             HIPCK(c, hipEventCreate(&a));
             HIPCK(c, hipEventCreate(&b));
             HIPCK(c, hipEventRecord(a, st));
           }
-          if (sacopt_launch_lms(sd.S, sd.D, (const LmsJob *)d_jobs[s], n_jobs[s], c->d_tab, c->bits, st)) { c->err = "k_lms launch failed"; return 1; }
+          if (sacopt_launch_lms(sd.S, sd.D, (const LmsJob *)d_jobs[s], n_jobs[s], c->d_tab, c->bits, st, L1C_WINDOW)) { c->err = "k_lms launch failed"; return 1; }
           if (dominant) {
             HIPCK(c, hipEventRecord(b, st));
             c->lms_ev.push_back({a, b});
@@ -986,7 +991,7 @@ static int final_pass_enqueue(sacopt_ctx *c, const ProfDesc &pd, const std::vect
     return 0;
   };
   // sA owns 32 CUs: right for a handful of frames (2 workgroups each), wrong for a large batch
-  const int lead_wgs = nch * (sacopt_lms_variant(pd.lms[0].S, pd.lms[0].D, nch, c->bits) ? 2 : 1);
+  const int lead_wgs = nch * (sacopt_lms_variant(pd.lms[0].S, pd.lms[0].D, nch, c->bits, L1C_FRAMES) ? 2 : 1);
   hipStream_t sLead = (c->sAall && lead_wgs > 32) ? c->sAall : c->sA;
   hipEvent_t ev_in;
   if (new_event(&ev_in)) return 1;
@@ -1009,13 +1014,13 @@ static int final_pass_enqueue(sacopt_ctx *c, const ProfDesc &pd, const std::vect
   for (int k = 0; k < nchunk; k++) {
     HIPCK(c, hipStreamWaitEvent(sLead, ev_lpc[k], 0));
     hipEvent_t a = nullptr, b = nullptr, e1;
-    const bool dominant = pd.lms[0].S != 1280 || sacopt_lms_variant(pd.lms[0].S, pd.lms[0].D, n_lms[0][k], c->bits) == c->timed_variant;
+    const bool dominant = pd.lms[0].S != 1280 || sacopt_lms_variant(pd.lms[0].S, pd.lms[0].D, n_lms[0][k], c->bits, L1C_FRAMES) == c->timed_variant;
     if (dominant) {
       HIPCK(c, hipEventCreate(&a));
       HIPCK(c, hipEventCreate(&b));
       HIPCK(c, hipEventRecord(a, sLead));
     }
-    if (sacopt_launch_lms(pd.lms[0].S, pd.lms[0].D, d_lms[0][k], n_lms[0][k], c->d_tab, c->bits, sLead)) { c->err = "k_lms launch failed"; return 1; }
+    if (sacopt_launch_lms(pd.lms[0].S, pd.lms[0].D, d_lms[0][k], n_lms[0][k], c->d_tab, c->bits, sLead, L1C_FRAMES)) { c->err = "k_lms launch failed"; return 1; }
     if (dominant) {
       HIPCK(c, hipEventRecord(b, sLead));
       c->lms_ev.push_back({a, b});
@@ -1028,7 +1033,7 @@ static int final_pass_enqueue(sacopt_ctx *c, const ProfDesc &pd, const std::vect
     // followers of chunk k together take no longer than the lead stage of chunk k+1
     hipStream_t fs = c->sB;
     for (int q = 1; q < pd.nlms; q++) {
-      if (sacopt_launch_lms(pd.lms[q].S, pd.lms[q].D, d_lms[q][k], n_lms[q][k], c->d_tab, c->bits, fs)) { c->err = "k_lms launch failed"; return 1; }
+      if (sacopt_launch_lms(pd.lms[q].S, pd.lms[q].D, d_lms[q][k], n_lms[q][k], c->d_tab, c->bits, fs, L1C_FRAMES)) { c->err = "k_lms launch failed"; return 1; }
       if (q == 1 && c->sD) {
         hipEvent_t e2;
         if (new_event(&e2)) return 1;
@@ -1183,7 +1188,7 @@ extern "C" int sacopt_predict_stereo_frames(sacopt_ctx *c, int profile, int nfra
   if (!get_prof(profile, &pd)) { c->err = "unknown profile"; return 1; }
   if (nframes < 0 || (nframes && (!frames || !out))) { c->err = "bad arguments"; return 1; }
   if (check_frames(c, nframes, frames, from, n)) return 1;
-  c->timed_variant = sacopt_lms_variant(1280, 640, nframes, c->bits);
+  c->timed_variant = sacopt_lms_variant(1280, 640, nframes, c->bits, L1C_FRAMES);
   double base[3 * SACOPT_MAX_COEFS];
   sacopt_base_profile(profile, base);
   size_t need = 1 << 20;
@@ -1530,7 +1535,7 @@ extern "C" int sacopt_encode_frames(sacopt_ctx *c, int profile, int nframes, con
   double prof[3 * SACOPT_MAX_COEFS];
   sacopt_base_profile(profile, prof);
   if (prof_in) memcpy(prof, prof_in, sizeof(double) * 3 * pd.ncoef);
-  c->timed_variant = sacopt_lms_variant(1280, 640, nframes, c->bits);
+  c->timed_variant = sacopt_lms_variant(1280, 640, nframes, c->bits, L1C_FRAMES);
   std::vector<std::vector<double>> grid;
   size_t total_cand = 0;
   if (ncoef_loop > 0 && build_grid(c, prof, ncoef_loop, grid, &total_cand)) return 1;
@@ -1832,7 +1837,7 @@ extern "C" int sacopt_lms_pair(sacopt_ctx *c, int S, int D, double mu1, double m
 #ifdef SACOPT_ABLATE
   if (const char *dbg = getenv("SACOPT_DBG")) sw = atoi(dbg) << 8;
 #endif
-  if (sacopt_launch_lms(S, D, dj, 1, c->d_tab, c->bits | sw, c->st)) { c->err = "unsupported (S,D) or launch failure"; return 1; }
+  if (sacopt_launch_lms(S, D, dj, 1, c->d_tab, c->bits | sw, c->st, L1C_FRAMES)) { c->err = "unsupported (S,D) or launch failure"; return 1; }
   HIPCK(c, hipEventRecord(b, c->st));
   c->lms_ev.push_back({a, b});
   if (copy_out(c, p0, j.p[0], (size_t)n * 8) || copy_out(c, p1, j.p[1], (size_t)n * 8)) return 1;
