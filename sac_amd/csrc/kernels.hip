@@ -323,6 +323,7 @@ struct SpecSum {
   double xs, xn;                       // walker, lane 4*s: x_s, the input of segment s, and x_{s+1}, the output it must produce
   int dS, dE;                          // walker, lane 4*s: their offsets on the candidate grids
   int sp, sd;                          // boundaries <= sp are exact; sd = offset of x_sp on its grid
+  int dw[NSEG + 1];                    // walker: the walked offsets d_2 .. d_NB, scalars until verify() needs them in lanes
   int walk_its;
 
   // P1, the four candidate waves (group 0..3) of the chain. sOut (optional): the last segment's outputs per candidate, as doubles --
@@ -390,20 +391,20 @@ struct SpecSum {
   }
 
   // walk d_{l+1} = step_l(d_l) for l >= sp, one boundary after the other on the scalar unit: the offset lives in an SGPR, a table
-  // look-up is a v_readlane with a computed lane (no LDS round trip, no cross-lane work) and the result goes to lanes 4*(l+1) (as
-  // that segment's input) and 4*l (as this segment's expected output) by v_writelane. Branches are what costs here (~25 cycles
+  // look-up is a v_readlane with a computed lane (no LDS round trip, no cross-lane work); the offsets stay scalars (dw) until
+  // verify() moves them to their lanes. Branches are what costs here (~25 cycles
   // each, taken or not), so the first walk (FIRST: sp == 1) has no start tests. Returns the offset at the last boundary.
   template <bool FIRST>
   __device__ __forceinline__ int walk() {
     int ds = sd;
     auto step = [&](auto lc) {
       constexpr int l = decltype(lc)::value;
-      const int mm = ds & 15, hi = ds - mm;
-      int t = __builtin_amdgcn_readlane(l < 4 ? tb0 : l < 8 ? tb1 : l < 12 ? tb2 : tb3, 16 * (l & 3) + mm);
-      if (hi) t += ((hi << __builtin_amdgcn_readlane(ksp, 4 * l)) + __builtin_amdgcn_readlane(krn, 4 * l)) >> __builtin_amdgcn_readlane(ksn, 4 * l);
+      int t = __builtin_amdgcn_readlane(l < 4 ? tb0 : l < 8 ? tb1 : l < 12 ? tb2 : tb3, 16 * (l & 3) + (ds & 15));
+      if ((unsigned)ds > 15u)  // off the grid (one compare on the way that stays on it; an index without the mask -- an add --
+                               // measured slower: a lane select fresh from a v_readlane costs wait states)
+        t += (((ds & ~15) << __builtin_amdgcn_readlane(ksp, 4 * l)) + __builtin_amdgcn_readlane(krn, 4 * l)) >> __builtin_amdgcn_readlane(ksn, 4 * l);
       ds = __builtin_amdgcn_readfirstlane(t);
-      asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(dS) : "s"(ds), "i"(4 * (l + 1)));
-      asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(dE) : "s"(ds), "i"(4 * l));
+      dw[l + 1] = ds;
       walk_its++;
     };
     if (FIRST) static_for<1, NB>(step);
@@ -418,6 +419,8 @@ struct SpecSum {
     const double x1 = *sX1;
     xs = sD == 1 ? x1 : 0.; xn = sD == 0 ? x1 : 0.;  // x_0 = +0 and x_1 are exact
     dS = 8; dE = 8;
+#pragma unroll
+    for (int l = 0; l <= NSEG; l++) dw[l] = 8;
     sp = 1;
     sd = __builtin_amdgcn_readlane(tb0, 0);
     return walk<true>();
@@ -429,6 +432,12 @@ struct SpecSum {
     double res = 0.;
     for (int guard = 0; guard < 17; guard++) {
       if (guard > 0) walk<false>();
+      // the walked offsets (scalars) to their lanes: 4*(l+1) as that segment's input, 4*l as this segment's expected output
+      static_for<1, NB>([&](auto lc) {
+        constexpr int l = decltype(lc)::value;
+        asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(dS) : "s"(dw[l + 1]), "i"(4 * (l + 1)));
+        asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(dE) : "s"(dw[l + 1]), "i"(4 * l));
+      });
       if (sD > sp) xs = gBase + (double)dS * gU;
       if (sD >= sp) xn = nB + (double)dE * nU;
       // every boundary at once (column 0 of every segment; the other columns sum from whatever they hold)
@@ -978,10 +987,11 @@ __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs
       ss.template candidates<true, true>((uint32_t)(uintptr_t)&prods2[t & 1][0], sJ, &sX1, sA, sOut, 0, true, lane, &ops);
       __syncthreads();
       double pv = 0.;
+      const double so = sOut[lane & 31];  // (fetched with the table: one LDS round trip less behind the walk)
       const int dl = ss.first_walk(sJ, &sX1, lane);
       int sf = 0;
       if ((unsigned)(dl + 8) < 32u) {  // (32 candidates at the last boundary: SpecSum::candidates<.., WIDE>)
-        pv = sOut[dl + 8];
+        pv = bcast(so, dl + 8);
         sf = 1;
         if (lane == 0) { predv = pv; specf = 1; }
       } else {  // the walk left the candidates at the last boundary: nothing to predict with
