@@ -24,7 +24,7 @@ extern "C" {
 int sacopt_lms_state_doubles(int S, int D);
 int sacopt_launch_lms(int S, int D, const LmsJob *jobs, int njobs, const uint16_t *tab, int bits, hipStream_t st, int limit);
 int sacopt_lms_variant(int S, int D, int njobs, int bits, int limit);
-// (1280,640) stage: k_lms1c gives a chain two CUs (4.98k cycles per sample against ~8.3k for both channels on one CU): taken
+// (1280,640) stage: k_lms1c gives a chain two CUs (4.85k cycles per sample against 7.74k for both channels on one CU): taken
 // for up to 20 chains per launch. Beyond that a call is throughput-bound and the two-channel kernel is cheaper per CU. (A window
 // evaluation with up to 96 chains on k_lms1c changed nothing for encode calls of 2..15 frames: the full-frame pass bounds them.)
 #define L1C_FRAMES 20
