@@ -266,7 +266,9 @@ def main():
                          "workgroups_per_launch": wgs if nfr <= 20 else None,
                          "frac_of_occupied_cus": achieved / (FP64_VECTOR_PEAK_TFLOPS * min(wgs, 256) / 256.0) if nfr <= 20 else None,
                          "avg_launch_ms": 1e3 * avg_launch_s, "launches": lms_launches,
-                         "units_per_launch": units_per_launch, "flops_per_unit": FLOPS_LMS1},
+                         "units_per_launch": units_per_launch, "flops_per_unit": FLOPS_LMS1,
+                         # serial latency of the dominant kernel: launch duration over the samples one chain advances in it
+                         "cycles_per_sample_at_2.4GHz": (avg_launch_s * 2.4e9 / (units_per_launch / nfr)) if (lms_launches and nfr <= 20) else None},
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cb = cpu_baseline()
