@@ -815,12 +815,10 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
 __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs, const uint16_t *__restrict__ gtab, int bits) {
   constexpr int S = 1280, T = 1920, NT = L1_NT, R = L1_R, CH = L1_CH, MO = L1_RLO - 1, MX = L1_RLX - 1;
   constexpr int SEG = L1_SEG, SEGP = L1_SEGP, NSEG = T / SEG;  // 15 segments of 128 products
+  __shared__ double prods[16 * SEGP];  // (one buffer also with early prediction: the verifier works from registers)
 #if L1_EARLY
-  __shared__ double prods2[2][16 * SEGP];  // products of sample t in [t & 1]: the walker verifies t while the tap waves write t + 1
   __shared__ double sOut[32], vexact;
   __shared__ int specf, vok;
-#else
-  __shared__ double prods[16 * SEGP];
 #endif
   __shared__ double sA[16];  // approximate segment sums (the guess of spec_exact_sum)
   __shared__ double ringo[L1_RLO];  // own channel's stage inputs   (taps 0..1279: lags 1..1280)
@@ -854,11 +852,7 @@ __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs
   for (int i = tid; i < (2 << bits); i += NT) tab[i] = gtab[i];
   for (int i = tid; i < L1_RLO; i += NT) ringo[i] = 0.;
   for (int i = tid; i < L1_RLX; i += NT) ringx[i] = 0.;
-#if L1_EARLY
-  for (int i = tid; i < 2 * 16 * SEGP; i += NT) (&prods2[0][0])[i] = 0.;  // chain 15 of the MFMA passes is idle: keep its operands finite
-#else
   for (int i = tid; i < 16 * SEGP; i += NT) prods[i] = 0.;  // chain 15 of the MFMA passes is idle: keep its operands finite
-#endif
   __syncthreads();
 
   double w[R], eg[R], mu[R];
@@ -927,7 +921,7 @@ __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs
   double h[R], wS[R], egS[R];
   long long n_spec = 0, n_redo = 0;  // (L1_PROF statistics)
   int pend = 0;  // the update of sample t - 1 used a prediction: its verification is due behind the next barrier
-  auto products = [&](int t) {  // w[i]*hist[i] (nlms.h:111) -> prods2[t & 1], approximate segment sum -> sA
+  auto products = [&](int t) {  // w[i]*hist[i] (nlms.h:111) -> prods, approximate segment sum -> sA
     double part = 0.;
 #pragma unroll
     for (int r = 0; r < R; r++)  // all history reads first: behind a product store the compiler would not move them
@@ -935,7 +929,7 @@ __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs
 #pragma unroll
     for (int r = 0; r < R; r++) {
       const double pr = w[r] * h[r];
-      if (valid[r]) prods2[t & 1][pa[r]] = pr;
+      if (valid[r]) prods[pa[r]] = pr;
       part = r ? part + pr : pr;
     }
     part = row_prefix16(part);  // tree order: a guess only
@@ -984,7 +978,7 @@ __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs
       L1_TICK(0)
       __syncthreads();
       if (pend && !vok) { n_redo++; __syncthreads(); }
-      ss.template candidates<true, true>((uint32_t)(uintptr_t)&prods2[t & 1][0], sJ, &sX1, sA, sOut, 0, true, lane, &ops);
+      ss.template candidates<true, true>((uint32_t)(uintptr_t)&prods[0], sJ, &sX1, sA, sOut, 0, true, lane, &ops);
       __syncthreads();
       double pv = 0.;
       const double so = sOut[lane & 31];  // (fetched with the table: one LDS round trip less behind the walk)
@@ -1025,7 +1019,7 @@ __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs
       __syncthreads();
       settle(t, true);
       if ((t & (CH - 1)) == 0 && t > t0) flush(t - CH, t);  // (behind the barrier: the last prediction of the block is the verifier's)
-      if (grp > 0) ss.template candidates<false, true>((uint32_t)(uintptr_t)&prods2[t & 1][0], sJ, &sX1, sA, sOut, grp, false, lane);
+      if (grp > 0) ss.template candidates<false, true>((uint32_t)(uintptr_t)&prods[0], sJ, &sX1, sA, sOut, grp, false, lane);
       __syncthreads();
       L1_TICK(1)
       __syncthreads();
