@@ -798,8 +798,11 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
 // the serial phases of one channel no longer wait for the other's verification retries.
 //
 // Per sample (3 barriers): products w[i]*hist[i] -> LDS (15 segments of 128, stride 130: bank-conflict-free
-// MFMA operand reads) | spec_exact_sum (waves 0..3 sum candidates, wave 0 walks and verifies) | update
-// (nlms.h:114-129, all threads). Predictions are buffered in LDS and written out once per 256 samples.
+// MFMA operand reads) | candidate pass (SpecSum: wave 15 -- no taps -- and waves 0..2) | wave 15 walks and publishes the sum the
+// walk predicts | update (nlms.h:114-129) with it by the tap waves while wave 15 verifies; redone from the kept weights in the
+// rare case that the prediction was not the exact sum (the loop below, L1_EARLY). The 512-thread build of tools/ has no spare
+// wave and keeps round 1's order: candidate pass | walk + verification | update. Predictions are buffered in LDS and written
+// out once per 256 samples.
 // ------------------------------------------------------------------------------------------
 #ifndef L1_NT
 #define L1_NT 1024
