@@ -617,7 +617,7 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
   long long hmiss = 0;
 #ifdef H_PROF  // phase clocks of every wave of the (256,128) stage (tools/h_phases.py): products | sums until the barrier | look-up (+ second pass) | update
   long long hp[4] = {0, 0, 0, 0}, hpT = clock64();
-#define H_TICK(i) { if (HALVES) { const long long now_ = clock64(); hp[i] += now_ - hpT; hpT = now_; } }
+#define H_TICK(i) { if (HALVES || SPEC) { const long long now_ = clock64(); hp[i] += now_ - hpT; hpT = now_; } }
 #else
 #define H_TICK(i)
 #endif
@@ -668,6 +668,7 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
         predv[sc] = res;
         pbuf[sc][t & (CH - 1)] = res;
       }
+      H_TICK(1)
     } else if constexpr (HALVES) {
       constexpr int H = H_SPLIT;  // terms of the first part (wave 0, from +0); the candidate waves sum the rest after guessing its sum
       if (wave == 0) {
@@ -761,6 +762,7 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
       }
     }
     __syncthreads();
+    if (SPEC) H_TICK(2)
     // ---- Update (nlms.h:114-129)
     const double e0 = ring[0][t & M] - predv[0];
     const double e1 = ring[1][t & M] - predv[1];
@@ -773,11 +775,12 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
         w[r] += (mu[r] * grad * rsq_emul2(eg[r] + 0.001, tab, bits));
       }
     }
+    if (SPEC) H_TICK(3)
   }
   if (HALVES) __syncthreads();
   if (tend > t0) flush((tend - 1) & ~(CH - 1), tend);
 #ifdef H_PROF
-  if (HALVES) { __syncthreads(); if (lane == 0 && tend - t0 >= 64) for (int i = 0; i < 4; i++) job.p[0][t0 + 4 * wave + i] = (double)hp[i]; }
+  if (HALVES || SPEC) { __syncthreads(); if (lane == 0 && tend - t0 >= 64) for (int i = 0; i < 4; i++) job.p[0][t0 + 4 * wave + i] = (double)hp[i]; }
 #endif
   if (HALVES && (dbg & 128)) {  // DEBUG: samples whose first half missed the candidates
     __syncthreads();
