@@ -242,6 +242,34 @@ __device__ __forceinline__ double mfma_pass32_regs(double acc, const Op32 &p) {
   return acc;
 }
 
+// mfma_pass32 with TWO accumulators per lane on the same operands: a candidate wave then carries 8 candidates per segment, two
+// waves the 16 of a chain -- half the LDS operand traffic of four waves, and the two MFMAs of a step do not wait for each other
+// (the two-channel kernel, where eight candidate waves shared four matrix pipes and the LDS).
+#define MF2(areg) "v_mfma_f64_4x4x4_4b_f64 %0, " areg ", %3, %0\n s_nop 1\n v_mfma_f64_4x4x4_4b_f64 %1, " areg ", %3, %1\n s_nop 1\n"
+__device__ __forceinline__ void mfma_pass32x2(uint32_t addr, double &acc0, double &acc1) {
+  double one = 1.0;
+  double a0, a1, a2, a3, a4, a5, a6, a7, b0, b1, b2, b3, b4, b5, b6, b7;
+  asm volatile(
+      "ds_read_b64 %4, %2 offset:0\n ds_read_b64 %5, %2 offset:32\n ds_read_b64 %6, %2 offset:64\n ds_read_b64 %7, %2 offset:96\n ds_read_b64 %8, %2 offset:128\n ds_read_b64 %9, %2 offset:160\n ds_read_b64 %10, %2 offset:192\n ds_read_b64 %11, %2 offset:224\n"
+      "ds_read_b64 %12, %2 offset:256\n ds_read_b64 %13, %2 offset:288\n ds_read_b64 %14, %2 offset:320\n ds_read_b64 %15, %2 offset:352\n ds_read_b64 %16, %2 offset:384\n ds_read_b64 %17, %2 offset:416\n ds_read_b64 %18, %2 offset:448\n ds_read_b64 %19, %2 offset:480\n"
+      "s_waitcnt lgkmcnt(8)\n s_nop 1\n"
+      MF2("%4") MF2("%5") MF2("%6") MF2("%7") MF2("%8") MF2("%9") MF2("%10") MF2("%11")
+      "ds_read_b64 %4, %2 offset:512\n ds_read_b64 %5, %2 offset:544\n ds_read_b64 %6, %2 offset:576\n ds_read_b64 %7, %2 offset:608\n ds_read_b64 %8, %2 offset:640\n ds_read_b64 %9, %2 offset:672\n ds_read_b64 %10, %2 offset:704\n ds_read_b64 %11, %2 offset:736\n"
+      "s_waitcnt lgkmcnt(8)\n s_nop 1\n"
+      MF2("%12") MF2("%13") MF2("%14") MF2("%15") MF2("%16") MF2("%17") MF2("%18") MF2("%19")
+      "ds_read_b64 %12, %2 offset:768\n ds_read_b64 %13, %2 offset:800\n ds_read_b64 %14, %2 offset:832\n ds_read_b64 %15, %2 offset:864\n ds_read_b64 %16, %2 offset:896\n ds_read_b64 %17, %2 offset:928\n ds_read_b64 %18, %2 offset:960\n ds_read_b64 %19, %2 offset:992\n"
+      "s_waitcnt lgkmcnt(8)\n s_nop 1\n"
+      MF2("%4") MF2("%5") MF2("%6") MF2("%7") MF2("%8") MF2("%9") MF2("%10") MF2("%11")
+      "s_waitcnt lgkmcnt(0)\n s_nop 1\n"
+      MF2("%12") MF2("%13") MF2("%14") MF2("%15") MF2("%16") MF2("%17") MF2("%18") MF2("%19")
+      "s_nop 7\n"
+      : "+v"(acc0), "+v"(acc1), "+v"(addr), "+v"(one), "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(a4), "=&v"(a5), "=&v"(a6),
+        "=&v"(a7), "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3), "=&v"(b4), "=&v"(b5), "=&v"(b6), "=&v"(b7)
+      :
+      : "memory");
+}
+#undef MF2
+
 #ifndef DPP_BC
 #define DPP_BC true
 #endif
@@ -330,7 +358,8 @@ struct SpecSum {
   // what the sum will be if the walk ends on candidate m.
   // WIDE: the idle sixteenth chain sums the LAST segment a second time, from 16 more candidates on either side of the grid
   // (grid indices -8..-1 and 16..23): sOut then has 32 entries, index = grid index + 8.
-  template <bool KEEP = false, bool WIDE = false>
+  // DUAL: two candidate waves (group 0, 1) with two accumulators each (mfma_pass32x2): candidates 8*group + 4*a + column.
+  template <bool KEEP = false, bool WIDE = false, bool DUAL = false>
   __device__ __forceinline__ void candidates(uint32_t prods_addr, int (*sJ)[16], double *sX1, const double *sA, double *sOut, int group,
                                              bool walker, int lane, Op32 *ops = nullptr) {
     const int jA = lane & 15, kA = lane >> 4;          // A-operand lane: chain jA, term 4s+kA of its segment at step s
@@ -368,8 +397,8 @@ struct SpecSum {
     gBase = prev - 8. * gU;
     nU = ulp_pow2(incl, &nIU);
     nB = incl - 8. * nU;
-    const int m16 = 4 * group + col;
-    int gi = m16;  // grid index of this lane's candidate
+    const int m16 = (DUAL ? 8 : 4) * group + col;
+    int gi = m16;  // grid index of this lane's (first) candidate
     if constexpr (WIDE) {
       const double gBq = row_shr<4>(gBase), gUq = row_shr<4>(gU);  // the quad before (all lanes shift: a DPP source lane must be active)
       if (sD == NSEG) { gBase = gBq; gU = gUq; gi = m16 < 8 ? m16 - 8 : m16 + 8; }  // the last boundary's grid
@@ -384,7 +413,14 @@ struct SpecSum {
       ksp = max(ks, 0); ksn = max(-ks, 0); krn = ksn ? 1 << (ksn - 1) : 0;
     }
     double o;
-    if constexpr (KEEP) o = mfma_pass32_keep(paddr, stv, *ops); else o = mfma_pass32(paddr, stv);
+    if constexpr (DUAL) {
+      static_assert(!KEEP && !WIDE, "DUAL is the plain candidate pass of the two-channel kernel");
+      double o2 = gBase + (double)(m16 + 4) * gU;
+      o = stv;
+      mfma_pass32x2(paddr, o, o2);
+      if (sD < NSEG) sJ[sD][m16 + 4] = (sD < NB) ? (int)((o2 - nB) * nIU) : 0;
+    } else if constexpr (KEEP) o = mfma_pass32_keep(paddr, stv, *ops);
+    else o = mfma_pass32(paddr, stv);
     if (sD < NSEG) sJ[sD][m16] = (sD < NB) ? (int)((o - nB) * nIU) : 0;
     if (sD == 0 && m16 == 0) *sX1 = o;  // segment 0 summed from +0: x_1, exact
     if (sOut && (sD == NB || (WIDE && sD == NSEG))) sOut[WIDE ? gi + 8 : m16] = o;
@@ -474,12 +510,12 @@ struct SpecSum {
   }
 };
 
-template <int NSEG, int STEPS, int SEGP>
+template <int NSEG, int STEPS, int SEGP, bool DUAL = false>
 __device__ __forceinline__ double spec_exact_sum(uint32_t prods_addr, int (*sJ)[16], double *sX1, const double *sA, int group,
                                                  bool walker, int dbg, long long &rounds, const int lane, int *hist = nullptr) {
   static_assert(STEPS == 32, "one pass = 32 MFMA steps");
   SpecSum<NSEG, SEGP> ss;
-  if (group >= 0) ss.candidates(prods_addr, sJ, sX1, sA, nullptr, group, walker, lane);
+  if (group >= 0) ss.template candidates<false, false, DUAL>(prods_addr, sJ, sX1, sA, nullptr, group, walker, lane);
   __syncthreads();
   double res = 0.;
   if (walker) {
@@ -499,6 +535,9 @@ __device__ __forceinline__ double spec_exact_sum(uint32_t prods_addr, int (*sJ)[
 // ------------------------------------------------------------------------------------------
 #define L1_SEG 128   // products per segment (32 MFMA steps)
 #define L1_SEGP 130  // segment stride in LDS: the 16 chain lanes of a ds_read_b64 half on 16 different 4-bank groups
+#ifndef S2_DUAL
+#define S2_DUAL 0  // two-channel (1280,640) kernel: two candidate waves per channel with two accumulators each
+#endif
 #ifndef H_SPLIT
 #define H_SPLIT 224  // (256,128) stage: terms summed from +0 by wave 0 (56 MFMA steps); the candidate waves guess that sum first, so they get the shorter rest (40 steps)
 #endif
@@ -661,9 +700,9 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
       static_assert(T == NSEG * SEG && NT * R == 4096 && (NT == 512 || NT == 1024), "SPEC is laid out for the (1280,640) stage, phases on waves 0..7");
       // waves 0..7: channel = wave & 1, candidate group = wave >> 1, so that the two channels' walkers (waves 0, 1)
       // and each channel's four candidate waves sit on different SIMDs
-      const int sc = wave & 1, grp = wave < 8 ? (wave >> 1) : -1;
+      const int sc = wave & 1, grp = wave < (S2_DUAL ? 4 : 8) ? (wave >> 1) : -1;
       long long rounds_ = 0;
-      const double res = spec_exact_sum<NSEG, SEG / 4, SEGP>((uint32_t)(uintptr_t)&prods[sc][0], sJ[sc], &sX1[sc], sA[sc], grp, grp == 0, dbg, rounds_, lane);
+      const double res = spec_exact_sum<NSEG, SEG / 4, SEGP, S2_DUAL>((uint32_t)(uintptr_t)&prods[sc][0], sJ[sc], &sX1[sc], sA[sc], grp, grp == 0, dbg, rounds_, lane);
       if (grp == 0 && lane == SPEC_RESULT_LANE(NSEG)) {
         predv[sc] = res;
         pbuf[sc][t & (CH - 1)] = res;
@@ -762,7 +801,7 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
       }
     }
     __syncthreads();
-    if (SPEC) H_TICK(2)
+    if (SPEC) { H_TICK(2) }
     // ---- Update (nlms.h:114-129)
     const double e0 = ring[0][t & M] - predv[0];
     const double e1 = ring[1][t & M] - predv[1];
@@ -775,7 +814,7 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
         w[r] += (mu[r] * grad * rsq_emul2(eg[r] + 0.001, tab, bits));
       }
     }
-    if (SPEC) H_TICK(3)
+    if (SPEC) { H_TICK(3) }
   }
   if (HALVES) __syncthreads();
   if (tend > t0) flush((tend - 1) & ~(CH - 1), tend);
