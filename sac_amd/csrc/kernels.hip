@@ -536,7 +536,7 @@ __device__ __forceinline__ double spec_exact_sum(uint32_t prods_addr, int (*sJ)[
 #define L1_SEG 128   // products per segment (32 MFMA steps)
 #define L1_SEGP 130  // segment stride in LDS: the 16 chain lanes of a ds_read_b64 half on 16 different 4-bank groups
 #ifndef S2_DUAL
-#define S2_DUAL 0  // two-channel (1280,640) kernel: two candidate waves per channel with two accumulators each
+#define S2_DUAL 1  // two-channel (1280,640) kernel: two candidate waves per channel with two accumulators each
 #endif
 #ifndef H_SPLIT
 #define H_SPLIT 224  // (256,128) stage: terms summed from +0 by wave 0 (56 MFMA steps); the candidate waves guess that sum first, so they get the shorter rest (40 steps)
