@@ -272,8 +272,8 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cb = cpu_baseline()
+            import subprocess
             try:  # frame-parallel on the box's CPU share (16 cores), as its own process: SURVEY §8d (ii)
-                import subprocess
                 out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cpu_baseline_mc.py"), "16", "32768"],
                                      capture_output=True, text=True, timeout=180)
                 line["cpu_baseline_all_cores"] = json.loads(out.stdout.strip().splitlines()[-1])
@@ -287,11 +287,22 @@ def main():
                 cores = 16
                 gpu_s = dt / args.steps
                 coder_s = cb["host_coder"]["seconds_per_frame"] * ((nfr + cores - 1) // cores)
-                line["end_to_end"] = {"cores": cores, "gpu_step_s": gpu_s, "host_coder_s": coder_s,
+                how = "the one-core measurement of cpu_baseline.host_coder x ceil(frames / cores)"
+                measured = None
+                try:  # measured: the clip's frames coded at once by `cores` processes (tools/host_coder_mc.py, its own process)
+                    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "host_coder_mc.py"), str(cores), str(nfr)],
+                                         capture_output=True, text=True, timeout=240)
+                    measured = json.loads(out.stdout.strip().splitlines()[-1])
+                    if "seconds" in measured:
+                        coder_s = measured["seconds"]
+                        how = f"measured: {measured['sample']}"
+                except Exception as e:
+                    measured = {"error": str(e)[:200]}
+                line["end_to_end"] = {"cores": cores, "gpu_step_s": gpu_s, "host_coder_s": coder_s, "host_coder_parallel": measured,
                                       "serial_samples_per_s": nfr * FRAME / (gpu_s + coder_s),
                                       "pipelined_samples_per_s": nfr * FRAME / max(gpu_s, coder_s),
                                       "note": "host coder = the reference's FrameCoder::Encode() (bit-plane + range coder, unchanged, on the host); "
-                                              "its time is the one-core measurement of cpu_baseline.host_coder x ceil(frames / cores)"}
+                                              "its time is " + how}
         if world == 1 and nfr == NFRAMES and not args.no_extras:
             line["apply_selected_parameters"] = apply_params_extra(ctx, torch, sacopt, b, nfr)
         if not args.no_large_batch and world == 1 and nfr == NFRAMES:
