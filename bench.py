@@ -114,6 +114,24 @@ def large_batch_extra(ctx, torch, dev, stereo_clip, sacopt, nfr=TRACK_FRAMES):
     return {"workload": f"{nfr} frames x {FRAME} (300 s track), same call", "ms": 1e3 * dt, "value": nfr * FRAME / dt, "unit": "samples/s"}
 
 
+def two_channel_extra(ctx, torch, dev, stereo_clip, sacopt, nch=21, n=16384):
+    """Not the headline: serial latency of the OTHER (1280,640) kernel -- both channels of a chain in one workgroup, what every
+    launch of more than 20 chains uses (the optimizer's rounds, large batches) -- from a full-frame pass of 21 short frames: its
+    lead stage is then that kernel, one workgroup per CU, and the library times those launches."""
+    L, R = stereo_clip(3000, nch * n)
+    dL = torch.from_numpy(L).to(dev); dR = torch.from_numpy(R).to(dev)
+    o = [torch.empty_like(dL) for _ in range(4)]
+    frames = [(dL.data_ptr() + 4 * f * n, dR.data_ptr() + 4 * f * n, n) for f in range(nch)]
+    outs = [dict(e0=o[0].data_ptr() + 4 * f * n, e1=o[1].data_ptr() + 4 * f * n, u0=o[2].data_ptr() + 4 * f * n, u1=o[3].data_ptr() + 4 * f * n)
+            for f in range(nch)]
+    for _ in range(2):
+        ctx.predict(sacopt.PROFILE_HIGH, frames, device_out=outs)
+    t = ctx.last_timing()
+    per_chain = t["lms_units"] / nch
+    return {"kernel": "k_lms<1280,640,512,8,2048,true>", "workload": f"full-frame pass of {nch} frames x {n} samples", "launches": t["lms_launches"],
+            "kernel_ms": t["lms_ms"], "cycles_per_sample_at_2.4GHz": t["lms_ms"] * 2.4e6 / per_chain if per_chain else None}
+
+
 def apply_params_extra(ctx, torch, sacopt, b, nfr):
     """Not the headline: SURVEY §8f.2's opt-in mode, where the stream is coded with the parameters Optimize selected: the
     full-frame pass depends on the optimizer's result, so the two cannot overlap (two library calls)."""
@@ -305,6 +323,8 @@ def main():
                                               "its time is " + how}
         if world == 1 and nfr == NFRAMES and not args.no_extras:
             line["apply_selected_parameters"] = apply_params_extra(ctx, torch, sacopt, b, nfr)
+        if world == 1 and nfr == NFRAMES and not args.no_extras:
+            line["two_channel_kernel"] = two_channel_extra(ctx, torch, dev, stereo_clip, sacopt)
         if not args.no_large_batch and world == 1 and nfr == NFRAMES:
             line["large_batch"] = large_batch_extra(ctx, torch, dev, stereo_clip, sacopt)   # untimed extra, not `value`
         if not args.no_decode and world == 1:
