@@ -282,6 +282,8 @@ extern "C" int sacopt_create(int device, const float *rsqrt_tab, int rsqrt_bits,
       // as its slowest workgroup, and the workgroups that shared a CU with a full-frame follower (busy all the time) were:
       // encode 554 -> 537 ms for 15 frames. With more lead workgroups than 192 CUs (or a chip that is full anyway) the
       // shared set is better (75 frames: 6.6 against 6.1 M samples/s).
+      // (Follower set of 16 or 48 CUs instead of 32: 486 / 541 against 428 ms for 15 frames -- masks that are not whole 32-bit words
+      // cut across the XCDs unevenly.)
       if (masked && prop.multiProcessorCount >= 256) {
         std::vector<uint32_t> mo(mr), mf(mr);
         for (int cu = 32; cu < prop.multiProcessorCount; cu++) {
