@@ -49,6 +49,23 @@ def test_lms_pair_hostile_inputs_vs_oracle(ctx, oracle, S, D, m1, m2):
     assert same_bits(p0, o0) and same_bits(p1, o1)
 
 
+@pytest.mark.parametrize("prof", [2, 1])
+def test_random_lengths_vs_oracle(ctx, oracle, prof):
+    # 28 clips of odd lengths (1 .. 30000 samples) in ONE call (more than 20 chains: the two-channel (1280,640) kernel) and every
+    # third one alone (k_lms1c): block edges (256), chunk edges (512, window chunks, the pipelined full-frame path beyond 16384)
+    rs = np.random.RandomState(5 + prof)
+    lens = [1, 2, 255, 256, 257, 511, 513, 4095, 4097, 16385] + [int(rs.randint(3, 3000)) for _ in range(10)] + \
+           [int(rs.randint(3000, 17000)) for _ in range(6)] + [int(rs.randint(17000, 30000)) for _ in range(2)]
+    clips = [stereo_clip(int(rs.randint(1, 1 << 30)), n) for n in lens]
+    res = ctx.predict(prof, clips)
+    for i, (L, R) in enumerate(clips):
+        ref = oracle.predict(prof, L, R)
+        assert same_bits(res[i]["e0"], ref["e0"]) and same_bits(res[i]["e1"], ref["e1"]), (i, len(L))
+        if i % 3 == 0:
+            one = ctx.predict(prof, [(L, R)])[0]
+            assert same_bits(one["e0"], ref["e0"]) and same_bits(one["e1"], ref["e1"]), (i, len(L))
+
+
 def test_lpc3_pair_golden(ctx, golden):
     p0, p1 = ctx.lpc3_pair(0.997, golden["pred_L"][:3000], golden["pred_R"][:3000])
     assert same_bits(p0, golden["lpc3_p0"]) and same_bits(p1, golden["lpc3_p1"])
