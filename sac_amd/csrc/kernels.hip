@@ -55,6 +55,31 @@ __device__ __forceinline__ double rsq_emul2(double a, const uint16_t *tab, int b
 }
 
 
+// rsq_emul2 for R arguments at once: the table reads are in flight together and one class test covers them all (a wave
+// that runs alone on its SIMD -- the (256,128) stage -- is bound by the latency of each tap's chain, not by issue).
+template <int R>
+__device__ __forceinline__ void rsq_emul2_n(const double (&a)[R], double (&out)[R], const uint16_t *tab, int bits) {
+  uint32_t u[R], tb[R];
+  bool special = false;
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    u[r] = __float_as_uint((float)a[r]);
+    const uint32_t off = (u[r] >> (22 - bits)) & (((2u << bits) - 1u) << 1);
+    tb[r] = RSQ_UNPACK(*reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(tab) + off));
+    special |= (u[r] & 0x7f800000u) == 0x7f800000u;
+  }
+#pragma unroll
+  for (int r = 0; r < R; r++) tb[r] += 0x20000000u - (((u[r] + 0x800000u) >> 1) & 0x7f800000u);
+  if (__builtin_amdgcn_ballot_w64(special) != 0ull) {
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int r = 0; r < R; r++)
+      if ((u[r] & 0x7f800000u) == 0x7f800000u) tb[r] = (u[r] & 0x7fffffu) ? (u[r] | 0x400000u) : 0u;  // NaN stays NaN, +inf -> +0
+  }
+#pragma unroll
+  for (int r = 0; r < R; r++) out[r] = (double)__uint_as_float(tb[r]);
+}
+
 // (int32_t)x as the reference's x86-64 build converts (cvttsd2si): anything outside int32, NaN included, becomes
 // INT32_MIN (the GPU's own conversion saturates). Only garbage residuals on the decoder side get there.
 __device__ __forceinline__ int32_t cvt_i32_x86(double x) {
@@ -538,6 +563,9 @@ __device__ __forceinline__ double spec_exact_sum(uint32_t prods_addr, int (*sJ)[
 #ifndef S2_DUAL
 #define S2_DUAL 1  // two-channel (1280,640) kernel: two candidate waves per channel with two accumulators each
 #endif
+#ifndef H_BATCH_RSQ
+#define H_BATCH_RSQ 1
+#endif
 #ifndef H_SPLIT
 #define H_SPLIT 224  // (256,128) stage: terms summed from +0 by wave 0 (56 MFMA steps); the candidate waves guess that sum first, so they get the shorter rest (40 steps)
 #endif
@@ -575,6 +603,7 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
   // output is the exact left-to-right sum of all 384 terms; if not, wave 0 sums the second half from the exact value
   // (48 more steps, as long as the undivided chain). Exactness never rests on the guess.
   constexpr bool HALVES = !SPEC && T == 384;
+  constexpr bool ALLVALID = !SPEC && NT * R == 2 * T;  // every tap slot is used: no per-slot validity tests (H_FAST)
   __shared__ double hX1[2], hOut[2][64], hGb[2], hIu[2], hU[2], hP2[2];
 
   const LmsJob job = jobs[blockIdx.x];
@@ -678,7 +707,7 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
 #pragma unroll
     for (int r = 0; r < R; r++) {
       const double pr = w[r] * h[r];
-      if (valid[r]) (&prods[0][0])[paddr[r]] = pr;
+      if (ALLVALID || valid[r]) (&prods[0][0])[paddr[r]] = pr;
       if (SPEC) part[BOTH ? (r >> 2) : 0] += pr;
     }
     if constexpr (SPEC) {
@@ -748,6 +777,7 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
       __syncthreads();
       double pr[2];
       bool miss = false;
+      const double xt0 = ring[0][t & M], xt1 = ring[1][t & M];  // (for the update: fetched with the look-up's first round trip)
 #pragma unroll
       for (int c = 0; c < 2; c++) {  // which candidate is the exact first part? (its start value recomputed as its wave computed it)
         const double x1 = hX1[c], gb = hGb[c];
@@ -768,16 +798,31 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
       if (tid < 2) pbuf[tid][t & (CH - 1)] = tid ? pr[1] : pr[0];
       H_TICK(2)
       // ---- Update (nlms.h:114-129)
-      const double e0 = ring[0][t & M] - pr[0];
-      const double e1 = ring[1][t & M] - pr[1];
+      const double e0 = xt0 - pr[0];
+      const double e1 = xt1 - pr[1];
+      if constexpr (ALLVALID && H_BATCH_RSQ) {  // the taps' chains side by side
+        if (!(dbg & 2)) {
+          double grad[R], arg[R], rs[R];
+#pragma unroll
+          for (int r = 0; r < R; r++) {
+            grad[r] = (cs[r] ? e1 : e0) * h[r];
+            eg[r] = 0.95 * eg[r] + (1.0 - 0.95) * (grad[r] * grad[r]);
+            arg[r] = eg[r] + 0.001;
+          }
+          rsq_emul2_n<R>(arg, rs, tab, bits);
+#pragma unroll
+          for (int r = 0; r < R; r++) w[r] += (mu[r] * grad[r] * rs[r]);
+        }
+      } else {
 #pragma unroll
       for (int r = 0; r < R; r++) {
-        if (valid[r] && !(dbg & 2)) {
+        if ((ALLVALID || valid[r]) && !(dbg & 2)) {
           const double err = cs[r] ? e1 : e0;
           const double grad = err * h[r];
           eg[r] = 0.95 * eg[r] + (1.0 - 0.95) * (grad * grad);
           w[r] += (mu[r] * grad * rsq_emul2(eg[r] + 0.001, tab, bits));
         }
+      }
       }
       H_TICK(3)
       continue;
