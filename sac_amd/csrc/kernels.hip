@@ -563,6 +563,9 @@ __device__ __forceinline__ double spec_exact_sum(uint32_t prods_addr, int (*sJ)[
 #ifndef S2_DUAL
 #define S2_DUAL 1  // two-channel (1280,640) kernel: two candidate waves per channel with two accumulators each
 #endif
+#ifndef UNCOND_UPDATE
+#define UNCOND_UPDATE 1
+#endif
 #ifndef H_BATCH_RSQ
 #define H_BATCH_RSQ 1
 #endif
@@ -852,7 +855,7 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
     const double e1 = ring[1][t & M] - predv[1];
 #pragma unroll
     for (int r = 0; r < R; r++) {
-      if (valid[r] && !(dbg & 2)) {
+      if ((UNCOND_UPDATE && SPEC || valid[r]) && !(dbg & 2)) {  // (SPEC: slots without a tap update scratch values of their own -- no exec masks)
         const double err = cs[r] ? e1 : e0;
         const double grad = err * h[r];
         eg[r] = 0.95 * eg[r] + (1.0 - 0.95) * (grad * grad);
@@ -1019,7 +1022,7 @@ __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs
 #pragma unroll
     for (int r = 0; r < R; r++) {
       const double pr = w[r] * h[r];
-      if (valid[r]) prods[pa[r]] = pr;
+      if (UNCOND_UPDATE || valid[r]) prods[pa[r]] = pr;  // (every wave of this loop carries taps)
       part = r ? part + pr : pr;
     }
     part = row_prefix16(part);  // tree order: a guess only
@@ -1031,13 +1034,13 @@ __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs
     lo = __builtin_amdgcn_update_dpp(0, lo, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2 and 3
     hi = __builtin_amdgcn_update_dpp(0, hi, 0x143, 0xC, 0xF, false);
     part += __hiloint2double(hi, lo);
-    if (hl == HW - 1 && valid[0]) sA[seg] = part;
+    if (hl == HW - 1 && (UNCOND_UPDATE || valid[0])) sA[seg] = part;
   };
   auto update = [&](int t, double pred, const double (&hh)[R]) {  // nlms.h:114-129
     const double err = ringo[t & MO] - pred;
 #pragma unroll
     for (int r = 0; r < R; r++) {
-      if (valid[r] && !(dbg & 2)) {
+      if ((UNCOND_UPDATE || valid[r]) && !(dbg & 2)) {
         const double grad = err * hh[r];
         eg[r] = 0.95 * eg[r] + (1.0 - 0.95) * (grad * grad);
         w[r] += (mu[r] * grad * rsq_emul2(eg[r] + 0.001, tab, bits));
