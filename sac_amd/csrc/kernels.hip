@@ -855,7 +855,7 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
     const double e1 = ring[1][t & M] - predv[1];
 #pragma unroll
     for (int r = 0; r < R; r++) {
-      if ((UNCOND_UPDATE && SPEC || valid[r]) && !(dbg & 2)) {  // (SPEC: slots without a tap update scratch values of their own -- no exec masks)
+      if ((UNCOND_UPDATE || valid[r]) && !(dbg & 2)) {  // (slots without a tap update scratch values of their own -- no exec masks)
         const double err = cs[r] ? e1 : e0;
         const double grad = err * h[r];
         eg[r] = 0.95 * eg[r] + (1.0 - 0.95) * (grad * grad);
