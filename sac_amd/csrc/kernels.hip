@@ -654,7 +654,7 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
     hoff[r] = (-lag) & M;
     paddr[r] = SPEC ? c * TP + (i / SEG) * SEGP + (i % SEG) : c * TP + i;
     w[r] = 0.; eg[r] = 0.;
-    if (!valid[r]) { hsel[r] = 0; hoff[r] = 0; paddr[r] = 0; }
+    if (!valid[r]) { hsel[r] = 0; hoff[r] = 0; if (!SPEC) paddr[r] = 0; }  // (SPEC: the idle sixteenth segment keeps its own product slots)
     if (t0 > 0 && job.state && valid[r]) {  // resume: weights / gradient energies of the previous chunk
       w[r] = job.state[tap[r]];
       eg[r] = job.state[R * NT + tap[r]];
@@ -710,7 +710,7 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
 #pragma unroll
     for (int r = 0; r < R; r++) {
       const double pr = w[r] * h[r];
-      if (ALLVALID || valid[r]) (&prods[0][0])[paddr[r]] = pr;
+      if (ALLVALID || (SPEC && UNCOND_UPDATE) || valid[r]) (&prods[0][0])[paddr[r]] = pr;  // (SPEC: the idle segment's slots take whatever its lanes compute)
       if (SPEC) part[BOTH ? (r >> 2) : 0] += pr;
     }
     if constexpr (SPEC) {
