@@ -598,7 +598,7 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
   __shared__ int sJ[2][SPEC ? 16 : 1][16];
   __shared__ double sX1[2];
   __shared__ double sA[2][16];  // SPEC: approximate segment sums (the guess of spec_exact_sum)
-  __shared__ uint16_t tab[RSQ_LDS_MAX];
+  __shared__ __attribute__((aligned(256))) uint16_t tab[RSQ_LDS_MAX];  // (most aligned = first in the LDS layout: its reads then take the base as an immediate offset)
   // HALVES (the (256,128) stage): the 384-term chain of a channel is cut in two. Wave 0 sums the first half exactly from
   // +0 while waves 1 and 2 sum the second half from 2 x 32 candidate inputs per channel around a guess of the first half's sum
   // (rows of the MFMA = channel x 8 candidate groups, its 4 output columns keep their own C: 64 accumulators = 2 x 32
