@@ -8,10 +8,19 @@ are NOT in the timed region (they stay on the host by the north star): `value` i
 `end_to_end` object prices the host coder beside it.
 
   N = 1  BASELINE.json configs[2]: one 60 s synthetic 16-bit 44.1 kHz stereo clip (15 frames x 176400).
-  N > 1  BASELINE.json configs[3]'s shape, weak-scaled: N five-minute tracks (75 frames x 176400 each; configs[3] is 64 of
-         them), the global frame list cut with sac_amd.dist.frame_shard (contiguous ranges, one per rank), one library
-         call of 75 frames per rank and step, the per-frame result rows (8 selected parameters + 4 maxbpn) all-gathered in
-         frame order with sac_amd.dist.gather_frame_rows over RCCL inside the timed region. No collective on the data path.
+  N > 1  BASELINE.json configs[3]'s shape, weak-scaled: N x T five-minute tracks (75 frames x 176400 each; configs[3] is 64
+         of them = T 8 on 8 GPUs; the default is --tracks-per-gpu 1, ONE EIGHTH of configs[3]'s per-GPU work, so that a step
+         stays at ~1.5 s), the global frame list cut with sac_amd.dist.frame_shard (contiguous ranges, one per rank), one
+         library call of 75 frames per track, the per-frame result rows (8 selected parameters + 4 maxbpn) all-gathered in
+         frame order with sac_amd.dist.gather_frame_rows (RCCL with --backend nccl) inside the timed region. No collective
+         on the data path.
+
+The timed step asks for everything the encoder's next stage consumes (src/codec.cpp:165-211): error, s2u_error,
+s2u_error_map (Remap::Analyse + Map on the device) and the four maxbpn.
+
+HIP runtime order: torch bundles its own libamdhip64; libsacopt.so binds to whichever runtime with that soname the process
+has loaded first. This program initialises torch's runtime FIRST and asserts that the process maps exactly one HIP runtime
+(sacopt.assert_single_hip_runtime) -- a swapped order fails there with a message instead of torch's "No HIP GPUs".
 
 Inputs are resident in HBM before the timed region. Prints ONE JSON line (rank 0).
 """
@@ -93,11 +102,26 @@ def decode_extra(ctx, torch, nfr, dL, dR, e0, e1):
 def make_batch(torch, dev, stereo_clip, seed, nfr):
     L, R = stereo_clip(seed, nfr * FRAME)
     dL = torch.from_numpy(L).to(dev); dR = torch.from_numpy(R).to(dev)
-    o = [torch.empty_like(dL) for _ in range(4)]
+    o = [torch.empty_like(dL) for _ in range(6)]   # error[2], s2u_error[2], s2u_error_map[2] (codec.cpp:165-204)
     frames = [(dL.data_ptr() + 4 * f * FRAME, dR.data_ptr() + 4 * f * FRAME, FRAME) for f in range(nfr)]
-    outs = [dict(e0=o[0].data_ptr() + 4 * f * FRAME, e1=o[1].data_ptr() + 4 * f * FRAME, u0=o[2].data_ptr() + 4 * f * FRAME,
-                 u1=o[3].data_ptr() + 4 * f * FRAME) for f in range(nfr)]
+    outs = [{k: o[i].data_ptr() + 4 * f * FRAME for i, k in enumerate(("e0", "e1", "u0", "u1", "m0", "m1"))} for f in range(nfr)]
     return dict(L=L, R=R, dL=dL, dR=dR, o=o, frames=frames, outs=outs)
+
+
+def check_frames_against_separate_calls(ctx, sacopt, b, best, which):
+    """The overlapped call's results for the frames `which` against FrameCoder::Optimize and PredictStereoFrame run as
+    separate library calls on those frames alone (another batch size: other kernels and stream sets): selected parameters
+    as bits, error / s2u_error / s2u_error_map and maxbpn of the whole frame."""
+    import torch  # noqa: F401
+    fr = [b["frames"][f] for f in which]
+    best_o, _, rows = ctx.optimize(sacopt.PROFILE_HIGH, fr)
+    ok = best_o.tobytes() == np.ascontiguousarray(best[which]).tobytes()
+    for i, f in enumerate(which):
+        chk = ctx.predict(sacopt.PROFILE_HIGH, [fr[i]], maps=True)[0]
+        for j, k in enumerate(("e0", "e1", "u0", "u1", "m0", "m1")):
+            ok = ok and np.array_equal(chk[k], b["o"][j][f * FRAME:(f + 1) * FRAME].cpu().numpy())
+        ok = ok and np.array_equal(chk["maxbpn"], b["maxbpn"][f])
+    return bool(ok), rows
 
 
 def large_batch_extra(ctx, torch, dev, stereo_clip, sacopt, nfr=TRACK_FRAMES):
@@ -108,10 +132,13 @@ def large_batch_extra(ctx, torch, dev, stereo_clip, sacopt, nfr=TRACK_FRAMES):
     ctx.encode(sacopt.PROFILE_HIGH, b["frames"], device_out=b["outs"])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    ctx.encode(sacopt.PROFILE_HIGH, b["frames"], device_out=b["outs"])
+    best, res = ctx.encode(sacopt.PROFILE_HIGH, b["frames"], device_out=b["outs"])
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    return {"workload": f"{nfr} frames x {FRAME} (300 s track), same call", "ms": 1e3 * dt, "value": nfr * FRAME / dt, "unit": "samples/s"}
+    b["maxbpn"] = [r["maxbpn"] for r in res]
+    ok, _ = check_frames_against_separate_calls(ctx, sacopt, b, best, [7, nfr - 1])
+    return {"workload": f"{nfr} frames x {FRAME} (300 s track), same call", "ms": 1e3 * dt, "value": nfr * FRAME / dt if ok else None,
+            "unit": "samples/s", "checked_against_separate_calls": ok}
 
 
 def two_channel_extra(ctx, torch, dev, stereo_clip, sacopt, nch=21, n=16384):
@@ -120,7 +147,7 @@ def two_channel_extra(ctx, torch, dev, stereo_clip, sacopt, nch=21, n=16384):
     lead stage is then that kernel, one workgroup per CU, and the library times those launches."""
     L, R = stereo_clip(3000, nch * n)
     dL = torch.from_numpy(L).to(dev); dR = torch.from_numpy(R).to(dev)
-    o = [torch.empty_like(dL) for _ in range(4)]
+    o = [torch.empty_like(dL) for _ in range(4)]   # (this extra times one kernel: no Remap outputs)
     frames = [(dL.data_ptr() + 4 * f * n, dR.data_ptr() + 4 * f * n, n) for f in range(nch)]
     outs = [dict(e0=o[0].data_ptr() + 4 * f * n, e1=o[1].data_ptr() + 4 * f * n, u0=o[2].data_ptr() + 4 * f * n, u1=o[3].data_ptr() + 4 * f * n)
             for f in range(nch)]
@@ -146,21 +173,44 @@ def apply_params_extra(ctx, torch, sacopt, b, nfr):
 
 
 def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes of this same command
-    (profiles/*_pmc_hbm.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); None if not collected."""
+    """HBM bytes per launch of the dominant kernel, (bytes, file): a STORED figure from the newest committed PMC pass of this
+    same command (profiles/rNN*_pmc_hbm.json, highest round prefix; FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, collected
+    in rocprofv3 --pmc runs of their own) -- a bench run cannot read the counters itself. (None, None) if not collected."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.json")))
-    if not files:
-        return None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]*_pmc_hbm.json")))
+    for path in reversed(files):
+        try:
+            with open(path) as f:
+                ks = json.load(f)["kernels"]
+            for name, v in ks.items():
+                if name.startswith("k_lms1c"):
+                    return v["hbm_bytes_per_dispatch"], os.path.relpath(path, ROOT)
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
+
+
+def host_cpu_model():
     try:
-        with open(files[-1]) as f:
-            ks = json.load(f)["kernels"]
-        for name, v in ks.items():
-            if name.startswith("k_lms1c"):
-                return v["hbm_bytes_per_dispatch"]
-    except (OSError, KeyError, ValueError):
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
         pass
-    return None
+    return "unknown"
+
+
+def split_extra(ctx, torch, sacopt, b):
+    """Not the headline: the two halves of the overlapped call alone (what bounds sacopt_encode_frames): FrameCoder::Optimize
+    of the clip, and the full-frame PredictStereoFrame of the clip with Remap outputs."""
+    out = {}
+    for name, fn in (("optimize_alone_ms", lambda: ctx.optimize(sacopt.PROFILE_HIGH, b["frames"])),
+                     ("full_frame_pass_alone_ms", lambda: ctx.predict(sacopt.PROFILE_HIGH, b["frames"], device_out=b["outs"]))):
+        fn(); torch.cuda.synchronize()
+        t0 = time.perf_counter(); fn(); torch.cuda.synchronize()
+        out[name] = 1e3 * (time.perf_counter() - t0)
+    return out
 
 
 def main():
@@ -169,6 +219,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frames", type=int, default=0, help="frames per GPU and step (default: 15 at N=1, 75 at N>1)")
+    ap.add_argument("--tracks-per-gpu", type=int, default=1, help="N > 1: five-minute tracks per GPU and step, one 75-frame library call each "
+                    "(BASELINE configs[3] = 64 tracks = 8 per GPU on 8 GPUs; default 1 = one eighth of that per-GPU work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true", help="skip the (untimed) decoder-side extra")
     ap.add_argument("--no-large-batch", action="store_true", help="skip the (untimed) 75-frame extra")
@@ -194,31 +246,45 @@ def main():
             dist.init_process_group(args.backend)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    torch.cuda.init()   # torch's HIP runtime first (see the module docstring); libsacopt.so is loaded after it and binds to it
+    torch.zeros(1, device=dev)
 
     from sac_amd import sacopt
     from sac_amd.dist import frame_shard, gather_frame_rows
     from sac_amd.synth import stereo_clip
 
-    per_gpu = args.frames or (NFRAMES if world == 1 else TRACK_FRAMES)
+    tracks = max(args.tracks_per_gpu, 1) if world > 1 else 1
+    per_call = args.frames or (NFRAMES if world == 1 else TRACK_FRAMES)   # frames per library call
+    per_gpu = per_call * tracks
     total_frames = per_gpu * world
-    lo, hi = frame_shard(total_frames, world, rank)      # contiguous frame range of this rank (= its own track at N > 1)
+    lo, hi = frame_shard(total_frames, world, rank)      # contiguous frame range of this rank (= its own tracks at N > 1)
     nfr = hi - lo
     b = make_batch(torch, dev, stereo_clip, 1000 + rank, nfr)
     frames, outs = b["frames"], b["outs"]
-    ctx = sacopt.Context(local_rank)   # rsqrtss table probed from this host's CPU, as the reference would see it
+    # rsqrtss table probed from this host's CPU, as the reference would see it (src/pred/nlms.h:34-57); recorded with the result
+    rsq_tab, rsq_bits = sacopt.probe_rsqrt()
+    ctx = sacopt.Context(local_rank, rsq_tab, rsq_bits)
+    sacopt.assert_single_hip_runtime()
+    import hashlib
+    rsq_sha = hashlib.sha256(np.ascontiguousarray(rsq_tab, dtype=np.float32).tobytes()).hexdigest()[:16]
 
     lms_ms = 0.0; lms_launches = 0; lms_units = 0
     table = None
 
     def step(timed):
         nonlocal lms_ms, lms_launches, lms_units, table
-        # FrameCoder::Predict with Optimize enabled: optimizer + final full-frame pass in one call
-        best, res = ctx.encode(sacopt.PROFILE_HIGH, frames, device_out=outs)
-        t1 = ctx.last_timing()
-        if timed:
-            lms_ms += t1["lms_ms"]
-            lms_launches += t1["lms_launches"]
-            lms_units += t1["lms_units"]
+        # FrameCoder::Predict with Optimize enabled: optimizer + final full-frame pass in one call (per track at N > 1)
+        bests, res = [], []
+        for c0 in range(0, nfr, per_call):
+            bb, rr = ctx.encode(sacopt.PROFILE_HIGH, frames[c0:c0 + per_call], device_out=outs[c0:c0 + per_call])
+            bests.append(bb); res += rr
+            t1 = ctx.last_timing()
+            if timed:
+                lms_ms += t1["lms_ms"]
+                lms_launches += t1["lms_launches"]
+                lms_units += t1["lms_units"]
+        best = np.concatenate(bests)
+        b["maxbpn"] = [r["maxbpn"] for r in res]
         if world > 1:   # what the writer rank needs from every frame, in frame order (RCCL all-gather of 96 B per frame)
             rows = np.concatenate([best, np.stack([r["maxbpn"] for r in res]).astype(np.float64)], axis=1)
             table = gather_frame_rows(rows, total_frames, world, rank)
@@ -248,10 +314,7 @@ def main():
     if args.no_extras:
         rows, verified = np.full(1, 84), None   # profiling runs: nothing but the timed steps touches the GPU
     else:
-        best_o, _, rows = ctx.optimize(sacopt.PROFILE_HIGH, frames[:2])
-        chk = ctx.predict(sacopt.PROFILE_HIGH, frames[:1])[0]
-        e0_enc = b["o"][0][:FRAME].cpu().numpy()
-        verified = bool(best_o.tobytes() == best[:2].tobytes() and np.array_equal(chk["e0"], e0_enc))
+        verified, rows = check_frames_against_separate_calls(ctx, sacopt, b, best, [0, nfr - 1] if nfr > 1 else [0])
     if world > 1:
         assert table is not None and table.shape == (total_frames, 12) and table[lo:hi, :8].tobytes() == best.tobytes()
     if rank == 0:
@@ -260,40 +323,47 @@ def main():
         avg_launch_s = (lms_ms / 1e3) / max(lms_launches, 1)
         units_per_launch = lms_units / max(lms_launches, 1)
         achieved = units_per_launch * FLOPS_LMS1 / avg_launch_s / 1e12 if lms_launches else 0.0
-        wgs = 2 * nfr if nfr <= 20 else nfr   # per-channel kernel: two workgroups per frame; two-channel kernel: one
+        nfr_call = min(nfr, per_call)
+        wgs = 2 * nfr_call if nfr_call <= 20 else nfr_call   # per-channel kernel: two workgroups per frame; two-channel kernel: one
+        traffic, traffic_file = pmc_traffic() if nfr_call <= 20 else (None, None)
         if world == 1:
             workload = (f"{nfr * 4} s synthetic 16-bit 44.1 kHz stereo clip ({nfr} frames x {FRAME}), high profile, full optimizer population "
                         f"({cand} GetCost per frame) + final full-frame predict (BASELINE configs[2]); range coding and file I/O excluded")
         else:
-            workload = (f"{world} synthetic 5-minute 16-bit 44.1 kHz stereo tracks ({TRACK_FRAMES if not args.frames else per_gpu} frames x {FRAME} each; BASELINE "
-                        f"configs[3]'s shape, one track per GPU instead of 64 in all), high profile, full optimizer population ({cand} GetCost per "
-                        "frame) + final full-frame predict; frames sharded with frame_shard, per-frame rows all-gathered over RCCL; range "
-                        "coding and file I/O excluded")
+            workload = (f"{world * tracks} synthetic 5-minute 16-bit 44.1 kHz stereo tracks ({per_call} frames x {FRAME} each), {tracks} per GPU "
+                        f"= {tracks}/8 of BASELINE configs[3]'s per-GPU work (64 tracks on 8 GPUs), one library call per track; high profile, full "
+                        f"optimizer population ({cand} GetCost per frame) + final full-frame predict with Remap outputs; frames sharded with "
+                        f"frame_shard, per-frame rows all-gathered over {'RCCL' if args.backend == 'nccl' else args.backend}; range coding and file I/O excluded")
         line = {
-            "metric": "encoded samples/sec (node) in optimize mode", "value": samples / dt, "unit": "samples/s",
+            "metric": "encoded samples/sec (node) in optimize mode", "value": samples / dt if verified is not False else None, "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": workload, "frames_per_gpu": nfr, "candidates_per_frame": cand,
+            "config": {"workload": workload, "frames_per_gpu": nfr, "frames_per_call": nfr_call, "tracks_per_gpu": tracks, "candidates_per_frame": cand,
+                       "outputs": "error, s2u_error, s2u_error_map, maxbpn, maxbpn_map per channel (codec.cpp:165-211) + 8 selected parameters per frame",
+                       "rsqrt_bits": int(rsq_bits), "rsqrt_table_sha256_16": rsq_sha, "host_cpu": host_cpu_model(),
                        "parallelism": f"frames sharded x{world}, no collective on the data path" + ("" if world == 1 else f"; result rows gathered over {args.backend}"), "checked_against_separate_calls": verified},
             "algorithmic_tflops_whole_path": cand_units * args.steps * FLOPS_UNIT_HIGH / dt / 1e12,
-            "roofline": {"bound": "mfma", "kernel": "k_lms1c" if nfr <= 20 else "k_lms<1280,640,512,8,2048,true> / k_lms1c (tail chunks)",
+            "roofline": {"bound": "mfma", "kernel": "k_lms1c" if nfr_call <= 20 else "k_lms<1280,640,512,8,2048,true> / k_lms1c (tail chunks)",
                          "note": "FP64 compute bound (78.6 TFLOP/s vector = matrix FP64 peak); the real ceiling is the dependent-add "
                                  "latency of the serial 1920-term sums, the matrix pipe is used as an exact f64 adder, not a GEMM",
                          "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_VECTOR_PEAK_TFLOPS, "traffic": pmc_traffic() if nfr <= 20 else None,
-                         "workgroups_per_launch": wgs if nfr <= 20 else None,
-                         "frac_of_occupied_cus": achieved / (FP64_VECTOR_PEAK_TFLOPS * min(wgs, 256) / 256.0) if nfr <= 20 else None,
+                         "frac": achieved / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic,
+                         "traffic_source": (traffic_file + " (stored PMC pass of this command, not this run)") if traffic_file else None,
+                         "workgroups_per_launch": wgs if nfr_call <= 20 else None,
+                         "frac_of_occupied_cus": achieved / (FP64_VECTOR_PEAK_TFLOPS * min(wgs, 256) / 256.0) if nfr_call <= 20 else None,
                          "avg_launch_ms": 1e3 * avg_launch_s, "launches": lms_launches,
                          "units_per_launch": units_per_launch, "flops_per_unit": FLOPS_LMS1,
                          # serial latency of the dominant kernel: launch duration over the samples one chain advances in it
-                         "cycles_per_sample_at_2.4GHz": (avg_launch_s * 2.4e9 / (units_per_launch / nfr)) if (lms_launches and nfr <= 20) else None},
+                         "cycles_per_sample_at_2.4GHz": (avg_launch_s * 2.4e9 / (units_per_launch / nfr_call)) if (lms_launches and nfr_call <= 20) else None},
         }
+        if verified is False:
+            line["error"] = "the overlapped call's results differ from FrameCoder::Optimize / PredictStereoFrame run separately: no value reported"
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cb = cpu_baseline()
             import subprocess
             try:  # frame-parallel on the box's CPU share (16 cores), as its own process: SURVEY §8d (ii)
-                out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cpu_baseline_mc.py"), "16", "32768"],
-                                     capture_output=True, text=True, timeout=180)
+                out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cpu_baseline_mc.py"), "16", str(FRAME)],
+                                     capture_output=True, text=True, timeout=300)
                 line["cpu_baseline_all_cores"] = json.loads(out.stdout.strip().splitlines()[-1])
             except Exception as e:  # a reported baseline, never the measurement
                 line["cpu_baseline_all_cores"] = {"error": str(e)[:200]}
@@ -322,6 +392,7 @@ def main():
                                       "note": "host coder = the reference's FrameCoder::Encode() (bit-plane + range coder, unchanged, on the host); "
                                               "its time is " + how}
         if world == 1 and nfr == NFRAMES and not args.no_extras:
+            line["split"] = split_extra(ctx, torch, sacopt, b)
             line["apply_selected_parameters"] = apply_params_extra(ctx, torch, sacopt, b, nfr)
         if world == 1 and nfr == NFRAMES and not args.no_extras:
             line["two_channel_kernel"] = two_channel_extra(ctx, torch, dev, stereo_clip, sacopt)
@@ -335,6 +406,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if verified is False:
+        sys.exit(1)
 
 
 if __name__ == "__main__":

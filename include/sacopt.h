@@ -7,8 +7,10 @@
  * All functions return 0 on success, non-zero on error (sacopt_last_error() has the text);
  * nothing throws across the ABI. Sample / residual pointers may be host or device
  * pointers (detected with hipPointerGetAttributes); host buffers are staged through
- * internal device buffers. One context per GPU; a context is not thread-safe, different
- * contexts are independent.
+ * internal device buffers. One context per GPU (or several: each has its own streams, arena and error text). A context
+ * is not thread-safe; different contexts are independent and may be driven from different threads at the same time
+ * (sacopt_last_error(NULL) is per thread). The one thing contexts of a GPU share is the static scratch of
+ * sacopt_cost_golomb_noalloc, which refuses overlapping calls.
  *
  * There is NO CPU fallback: every entry point fails if no gfx950 device is usable.
  */
@@ -161,13 +163,15 @@ int sacopt_coded_sizes(sacopt_ctx *ctx, int nbuf, const int32_t *const *s2u, con
 
 /* ---- CostGolomb::Calc without any allocation ------------------------------------------------------------------
  * NO COUNTERPART IN THE REFERENCE. Same arguments, result and state handling as sacopt_cost_golomb, for callers that
- * cannot allocate: code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc. The staging copy of
- * a host `buf` and the kernels' partial results (the buffer is costed in parallel segments whose guessed start states are
- * verified, see kernels.hip) live in a file-scope device array of 4 MiB + 1.6 KiB that every GPU the library runs on
- * holds until the process ends; the call makes no hipMalloc / hipFree / hipHostMalloc, creates no event and touches
- * neither the context's arena nor its staging memory. Limits: n <= SACOPT_NOALLOC_MAX_SAMPLES (larger n is an error, as
- * is a NULL ctx); all calls on one GPU -- from any context -- share that GPU's array, so calls that overlap on one GPU
- * race: serialise them. */
+ * cannot allocate: callable while allocation is forbidden -- for example while ANOTHER stream of the process is being
+ * captured into a HIP graph, in tight serving loops, under harnesses that forbid hipMalloc. The call itself is blocking
+ * (it synchronises the library's private stream and copies its two result doubles to the caller) and is NOT capturable.
+ * The staging copy of a host `buf` and the kernels' partial results (the buffer is costed in parallel segments whose
+ * guessed start states are verified, see kernels.hip) live in a file-scope device array of 4 MiB + 1.6 KiB that every GPU
+ * the library runs on holds until the process ends; the call makes no hipMalloc / hipFree / hipHostMalloc, creates no
+ * event and touches neither the context's arena nor its staging memory. Limits: n <= SACOPT_NOALLOC_MAX_SAMPLES (larger n
+ * is an error, as is a NULL ctx); all calls on one GPU -- from any context -- share that GPU's array: a call that finds it
+ * in use by another context or thread returns an error ("already running on this GPU") instead of racing. */
 #define SACOPT_NOALLOC_MAX_SAMPLES (1 << 20)
 int sacopt_cost_golomb_noalloc(sacopt_ctx *ctx, const int32_t *buf, int n, double *state_inout, double *cost);
 

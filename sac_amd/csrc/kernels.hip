@@ -16,6 +16,7 @@
 // chains run on the matrix pipe as *adders*, not as a GEMM.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include <type_traits>
 #include "jobs.h"
 
@@ -2075,14 +2076,16 @@ extern "C" int sacopt_launch_cost_par(const CostJob *jobs, int njobs, int nbuf, 
 // ---- the entry point that allocates nothing (sacopt_cost_golomb_noalloc) -------------------------------------------------
 // Device address of `scratch` on the CURRENT device, looked up once per device (every GPU has its own copy at its own address).
 extern "C" int sacopt_noalloc_scratch(int device, void **ptr, size_t *stage_bytes, size_t *ctl_doubles, int *max_n) {
-  static void *dev_ptr[64];  // per device; written once under the caller's create call (sacopt_create is not re-entrant per device)
+  // per device; contexts may be created from several threads at once: two threads that both find it empty look the same
+  // address up and store the same value
+  static std::atomic<void *> dev_ptr[64];
   if (device < 0 || device >= 64) return 1;
-  if (!dev_ptr[device]) {
-    void *p = nullptr;
+  void *p = dev_ptr[device].load(std::memory_order_acquire);
+  if (!p) {
     if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess || !p) { (void)hipGetLastError(); return 1; }
-    dev_ptr[device] = p;
+    dev_ptr[device].store(p, std::memory_order_release);
   }
-  *ptr = dev_ptr[device];
+  *ptr = p;
   *stage_bytes = NOALLOC_STAGE_BYTES;
   *ctl_doubles = NOALLOC_CTL_DOUBLES;
   *max_n = NOALLOC_MAX_N;

@@ -8,6 +8,7 @@
 // (bit-identical to the reference, which recomputes everything: src/codec.cpp:341-352).
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -48,7 +49,10 @@ int sacopt_noalloc_scratch(int device, void **ptr, size_t *stage_bytes, size_t *
 int sacopt_launch_cost_noalloc(const int32_t *e, int n, double *ctl, const int *pow2_bits, hipStream_t st);
 }
 
-static thread_local std::string g_create_error;
+static thread_local std::string g_create_error;  // error text of a failed sacopt_create on THIS thread
+// sacopt_cost_golomb_noalloc: every context on a GPU shares that GPU's static scratch. A call that finds the scratch in use
+// (another context / thread on the same GPU) returns an error instead of racing on it.
+static std::atomic_flag g_na_busy[64] = {};
 
 struct sacopt_ctx {
   int device = 0;
@@ -60,7 +64,10 @@ struct sacopt_ctx {
   hipStream_t up = nullptr;                // stream of upload() (NULL: st); the full-frame pipeline stages its job tables on sB
   hipStream_t sAall = nullptr;             // lead stage of the full-frame pass when it has more workgroups than sA's reserved CUs
   hipStream_t sD = nullptr;                // final-pass pipeline: stages behind the second LMS stage (may be NULL)
-  std::vector<hipEvent_t> pipe_ev;         // events of the last call's pipeline
+  // Events are created once and reused from call to call (a 15-frame encode call records several hundred): two pools, with
+  // and without timing, handed out in order and taken back as a whole by begin_call once every stream is idle.
+  std::vector<hipEvent_t> ev_timed, ev_plain;
+  size_t ev_timed_used = 0, ev_plain_used = 0;
   uint16_t *d_tab = nullptr;  // rsqrtss table, RSQ_PACK'ed
   int bits = 0;
   int *d_pow2 = nullptr;
@@ -103,6 +110,7 @@ struct sacopt_ctx {
   int na_max_n = 0;
 };
 
+static hipEvent_t take_event(sacopt_ctx *c, bool timed);
 #define HIPCK(ctx, call)                                                                          \
   do {                                                                                            \
     hipError_t e_ = (call);                                                                       \
@@ -110,6 +118,24 @@ struct sacopt_ctx {
       (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                             \
       return 1;                                                                                   \
     }                                                                                             \
+  } while (0)
+
+// An event from the context's pool (nullptr: creation failed, c->err set). Valid until the next begin_call.
+static hipEvent_t take_event(sacopt_ctx *c, bool timed) {
+  std::vector<hipEvent_t> &pool = timed ? c->ev_timed : c->ev_plain;
+  size_t &used = timed ? c->ev_timed_used : c->ev_plain_used;
+  if (used == pool.size()) {
+    hipEvent_t e = nullptr;
+    const hipError_t rc = timed ? hipEventCreate(&e) : hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    if (rc != hipSuccess) { c->err = std::string("hipEventCreate: ") + hipGetErrorString(rc); return nullptr; }
+    pool.push_back(e);
+  }
+  return pool[used++];
+}
+#define TAKE_EVENT(ctx, var, timed)                 \
+  do {                                              \
+    (var) = take_event((ctx), (timed));             \
+    if (!(var)) return 1;                           \
   } while (0)
 
 // ------------------------------------------------------------------------------------------ rsqrtss
@@ -252,7 +278,9 @@ extern "C" int sacopt_create(int device, const float *rsqrt_tab, int rsqrt_bits,
 #ifdef SACOPT_ABLATE  // tools/ builds only: kernel-variant switches for A/B timing (kernels.hip). The product library reads no such variable.
   if (const char *dbg = getenv("SACOPT_DBG_ALL")) c->bits |= atoi(dbg) << 8;
 #endif
-  auto fail = [&](const char *what) { g_create_error = what; delete c; return 1; };
+  // sacopt_destroy copes with a half-built context (every member starts null): streams, tables and events created before
+  // the failing step are released with it
+  auto fail = [&](const char *what) { g_create_error = what; sacopt_destroy(c); return 1; };
   if (hipSetDevice(device) != hipSuccess) return fail("hipSetDevice failed");
   // Streams and hardware queues. HIP multiplexes same-priority streams onto a small pool of in-order hardware
   // queues (3 usable here: a 4th normal-priority stream shared a queue with the pre-enqueued full-frame
@@ -364,8 +392,10 @@ extern "C" int sacopt_create(int device, const float *rsqrt_tab, int rsqrt_bits,
 extern "C" void sacopt_destroy(sacopt_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  if (c->st) (void)hipStreamSynchronize(c->st);
-  for (auto &p : c->lms_ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+  for (hipStream_t q : {c->st, c->sA, c->sAall, c->sB, c->sC, c->sD, c->sE, c->split[0], c->split[1], c->split[2], c->split[3], c->split[4]})
+    if (q) (void)hipStreamSynchronize(q);
+  for (hipEvent_t e : c->ev_timed) (void)hipEventDestroy(e);
+  for (hipEvent_t e : c->ev_plain) (void)hipEventDestroy(e);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->arena) (void)hipFree(c->arena);
@@ -375,7 +405,6 @@ extern "C" void sacopt_destroy(sacopt_ctx *c) {
   if (c->d_bp_fwd) (void)hipFree(c->d_bp_fwd);
   if (c->d_bp_inv) (void)hipFree(c->d_bp_inv);
   if (c->d_bp_sse) (void)hipFree(c->d_bp_sse);
-  for (hipEvent_t e : c->pipe_ev) (void)hipEventDestroy(e);
   if (c->sA) (void)hipStreamDestroy(c->sA);
   if (c->sB) (void)hipStreamDestroy(c->sB);
   if (c->sC) (void)hipStreamDestroy(c->sC);
@@ -479,10 +508,8 @@ static int begin_call(sacopt_ctx *c) {
     if (hipHostMalloc((void **)&p, tot, hipHostMallocDefault) == hipSuccess) c->pins.push_back({p, tot, 0});
     else (void)hipGetLastError();
   } else if (!c->pins.empty()) c->pins[0].used = 0;
-  for (auto &p : c->lms_ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
-  c->lms_ev.clear();
-  for (hipEvent_t e : c->pipe_ev) (void)hipEventDestroy(e);
-  c->pipe_ev.clear();
+  c->lms_ev.clear();  // every stream is idle: all pooled events are free again
+  c->ev_timed_used = c->ev_plain_used = 0;
   c->total_ms = c->lms_ms = 0;
   c->lms_launches = 0;
   c->lms_units = 0;
@@ -777,8 +804,8 @@ static int eval_chains(sacopt_ctx *c, const ProfDesc &pd, const std::vector<DevF
           const bool dominant = (s == 1) && (sd.S != 1280 || sacopt_lms_variant(sd.S, sd.D, n_jobs[s], c->bits, L1C_WINDOW) == c->timed_variant);
           hipEvent_t a = nullptr, b = nullptr;
           if (dominant) {
-            HIPCK(c, hipEventCreate(&a));
-            HIPCK(c, hipEventCreate(&b));
+            TAKE_EVENT(c, a, true);
+            TAKE_EVENT(c, b, true);
             HIPCK(c, hipEventRecord(a, st));
           }
           if (sacopt_launch_lms(sd.S, sd.D, (const LmsJob *)d_jobs[s], n_jobs[s], c->d_tab, c->bits, st, L1C_WINDOW)) { c->err = "k_lms launch failed"; return 1; }
@@ -793,15 +820,13 @@ static int eval_chains(sacopt_ctx *c, const ProfDesc &pd, const std::vector<DevF
       }
       if (s == lead && lead < nstage - 1) {
         hipEvent_t e;
-        HIPCK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        c->pipe_ev.push_back(e);
+        TAKE_EVENT(c, e, false);
         HIPCK(c, hipEventRecord(e, c->st));
         HIPCK(c, hipStreamWaitEvent(c->sC, e, 0));
       }
       if (s == lead + 1 && c->sE && s < nstage - 1) {
         hipEvent_t e;
-        HIPCK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        c->pipe_ev.push_back(e);
+        TAKE_EVENT(c, e, false);
         HIPCK(c, hipEventRecord(e, c->sC));
         HIPCK(c, hipStreamWaitEvent(c->sE, e, 0));
       }
@@ -809,8 +834,7 @@ static int eval_chains(sacopt_ctx *c, const ProfDesc &pd, const std::vector<DevF
   }
   if (lead < nstage - 1) {  // join: c->st continues (cost kernel, copies) after the follower stages
     hipStream_t lasts = (c->sE && lead + 1 < nstage - 1) ? c->sE : c->sC;
-    HIPCK(c, hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
-    c->pipe_ev.push_back(ev_join);
+    TAKE_EVENT(c, ev_join, false);
     HIPCK(c, hipEventRecord(ev_join, lasts));
     HIPCK(c, hipStreamWaitEvent(c->st, ev_join, 0));
   }
@@ -990,8 +1014,7 @@ static int final_pass_enqueue(sacopt_ctx *c, const ProfDesc &pd, const std::vect
   }
   // ---- enqueue
   auto new_event = [&](hipEvent_t *e) -> int {
-    HIPCK(c, hipEventCreateWithFlags(e, hipEventDisableTiming));
-    c->pipe_ev.push_back(*e);
+    TAKE_EVENT(c, *e, false);
     return 0;
   };
   // sA owns 32 CUs: right for a handful of frames (2 workgroups each), wrong for a large batch
@@ -1020,8 +1043,8 @@ static int final_pass_enqueue(sacopt_ctx *c, const ProfDesc &pd, const std::vect
     hipEvent_t a = nullptr, b = nullptr, e1;
     const bool dominant = pd.lms[0].S != 1280 || sacopt_lms_variant(pd.lms[0].S, pd.lms[0].D, n_lms[0][k], c->bits, L1C_FRAMES) == c->timed_variant;
     if (dominant) {
-      HIPCK(c, hipEventCreate(&a));
-      HIPCK(c, hipEventCreate(&b));
+      TAKE_EVENT(c, a, true);
+      TAKE_EVENT(c, b, true);
       HIPCK(c, hipEventRecord(a, sLead));
     }
     if (sacopt_launch_lms(pd.lms[0].S, pd.lms[0].D, d_lms[0][k], n_lms[0][k], c->d_tab, c->bits, sLead, L1C_FRAMES)) { c->err = "k_lms launch failed"; return 1; }
@@ -1585,8 +1608,7 @@ extern "C" int sacopt_encode_frames(sacopt_ctx *c, int profile, int nframes, con
   const bool opt_first = ncoef_loop > 0 && final_pass_pipelined(pd, fr, chains);
   hipEvent_t staged = nullptr;
   if (opt_first) {
-    HIPCK(c, hipEventCreateWithFlags(&staged, hipEventDisableTiming));
-    c->pipe_ev.push_back(staged);
+    TAKE_EVENT(c, staged, false);
     HIPCK(c, hipEventRecord(staged, c->st));
   } else if (run_final_pass(c, pd, fr, chains, &done)) return 1;
   if (ncoef_loop > 0) {  // Optimize on the centre window (codec.cpp:356-359)
@@ -1669,8 +1691,8 @@ extern "C" int sacopt_unpredict_stereo_frames(sacopt_ctx *c, int profile, int nf
   UnJob *dj;
   if (upload(c, jobs, &dj)) return 1;
   hipEvent_t a, b;
-  HIPCK(c, hipEventCreate(&a));
-  HIPCK(c, hipEventCreate(&b));
+  TAKE_EVENT(c, a, true);
+  TAKE_EVENT(c, b, true);
   HIPCK(c, hipEventRecord(a, c->st));
   // one workgroup per frame, a CU each: launch on the stream that may use every CU (c->st leaves out the CUs reserved for
   // the encoder's lead stage), ordered behind the uploads and in front of the copies by events
@@ -1732,6 +1754,9 @@ extern "C" int sacopt_cost_golomb_noalloc(sacopt_ctx *c, const int32_t *buf, int
   if (n < 0 || !cost || (n && !buf)) { c->err = "bad arguments"; return 1; }
   if (n > c->na_max_n) { c->err = "sacopt_cost_golomb_noalloc: n exceeds the static scratch (at most 1048576 samples per call)"; return 1; }
   if (n == 0) { *cost = 0.; return 0; }  // codec.cpp:335: empty buffer -> 0, state untouched
+  if (c->device < 0 || c->device >= 64) { c->err = "sacopt_cost_golomb_noalloc: device index beyond the scratch table"; return 1; }
+  if (g_na_busy[c->device].test_and_set(std::memory_order_acquire)) { c->err = "sacopt_cost_golomb_noalloc already running on this GPU (all contexts of a GPU share its static scratch: serialise the calls)"; return 1; }
+  struct Release { int d; ~Release() { g_na_busy[d].clear(std::memory_order_release); } } release{c->device};
   HIPCK(c, hipStreamSynchronize(c->st));  // an earlier call that failed half-way may have left work on the stream
   double *ctl = reinterpret_cast<double *>(c->na_scratch + c->na_stage_bytes);
   const int32_t *d = buf;
@@ -1785,8 +1810,8 @@ extern "C" int sacopt_coded_sizes(sacopt_ctx *c, int nbuf, const int32_t *const 
   int32_t *dsz = arena_alloc<int32_t>(c, nbuf);
   if (!T || !msb || !sse || !lb || !dsz) { c->err = "device arena exhausted"; return 1; }
   hipEvent_t a, b2;
-  HIPCK(c, hipEventCreate(&a));
-  HIPCK(c, hipEventCreate(&b2));
+  TAKE_EVENT(c, a, true);
+  TAKE_EVENT(c, b2, true);
   HIPCK(c, hipEventRecord(a, c->st));
   if (sacopt_launch_bpsize(dj, nbuf, maxn, maxplanes, T, msb, sse, lb, c->d_bp_fwd, c->d_bp_inv, c->d_bp_sse, c->bp_tscale, c->bp_xscale, dsz, c->st)) { c->err = "k_bpsize launch failed"; return 1; }
   HIPCK(c, hipEventRecord(b2, c->st));
@@ -1834,8 +1859,8 @@ extern "C" int sacopt_lms_pair(sacopt_ctx *c, int S, int D, double mu1, double m
   LmsJob *dj;
   if (upload(c, jobs, &dj)) return 1;
   hipEvent_t a, b;
-  HIPCK(c, hipEventCreate(&a));
-  HIPCK(c, hipEventCreate(&b));
+  TAKE_EVENT(c, a, true);
+  TAKE_EVENT(c, b, true);
   HIPCK(c, hipEventRecord(a, c->st));
   int sw = 0;
 #ifdef SACOPT_ABLATE

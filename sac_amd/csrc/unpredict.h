@@ -64,8 +64,13 @@ __device__ __forceinline__ int unmap_wave(const uint32_t *mp, int pred, int merr
   }
   w = __builtin_amdgcn_readfirstlane(w);
   const long long x = 32ll * w + kth_set_bit(bw[w], kglob - (int)rk[w]);
-  const long long d = sgn > 0 ? x - ip : ip - x;  // |pred| < 2^31 and x in 0..65536: fits int32 after the sign
-  return (int)(sgn * d);
+  // d = distance walked. x is in 0..65536 but pred is any int32 (a garbage stream reaches INT32_MIN through cvt_i32_x86), so
+  // d can reach 2^31 + 32768: beyond int32. The reference's `pred + sgn * err` is signed overflow (undefined behaviour) in
+  // exactly those cases, so there is nothing to pin ("parity unpinned" there): the step wraps modulo 2^32, which is what the
+  // oracle's (int32_t) cast and the reference's compiled code (two's-complement add) do in practice
+  // (tests/test_gpu_unpredict.py::test_unpredict_unmap_out_of_table decodes garbage streams whose predictions leave the table).
+  const long long d = sgn > 0 ? x - ip : ip - x;
+  return (int)(unsigned)(unsigned long long)(sgn * d);
 }
 
 // Out of line: the factorisation holds a matrix row and a solution row per lane (96 VGPRs). Inlined, the allocator

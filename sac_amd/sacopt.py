@@ -81,6 +81,30 @@ EXPORTS = ["sacopt_create", "sacopt_destroy", "sacopt_last_error", "sacopt_probe
            "sacopt_cascade_trace", "sacopt_last_timing"]
 
 
+def hip_runtimes_mapped():
+    """Paths of the libamdhip64 files this process has mapped."""
+    out = set()
+    try:
+        with open("/proc/self/maps") as f:
+            for ln in f:
+                if "libamdhip64" in ln:
+                    out.add(ln.split()[-1])
+    except OSError:
+        pass
+    return sorted(out)
+
+
+def assert_single_hip_runtime():
+    """torch bundles its own libamdhip64 (needed as `libamdhip64.so`), libsacopt.so needs `libamdhip64.so.7`. The dynamic loader
+    gives libsacopt the runtime torch has already loaded (its soname matches) -- ONE runtime, everything works. The other
+    way round (libsacopt first, then torch) the process ends up with two runtimes and torch's finds no GPU. So, in a process
+    that uses both: initialise torch.cuda BEFORE the first sacopt.lib() / Context(). This raises if two runtimes are mapped."""
+    r = hip_runtimes_mapped()
+    if len(r) > 1:
+        raise RuntimeError("two HIP runtimes in this process (%s): import torch and touch torch.cuda BEFORE sac_amd.sacopt "
+                           "loads libsacopt.so" % ", ".join(r))
+
+
 def _p(a):
     """numpy array -> host pointer; int -> raw (device) pointer; None -> NULL."""
     if a is None:

@@ -31,6 +31,52 @@ class _DevBuf:
         self.hip.hipFree(self.ptr)
 
 
+def test_no_alloc_vs_oracle_and_sequential_fallback(rsqrt_table, oracle):
+    # directly against the oracle's CostGolomb::Calc (codec.cpp:315-339), and the branch of k_cseg_fin where a guessed segment
+    # state is wrong: >= 4096 zero residuals in front of a 16384-sample boundary make the guess exactly 0.0 while the true
+    # mean is m * 0.98^k > 0, so the verification fails and one wave walks the whole buffer again
+    with sacopt.Context(0, *rsqrt_table) as c:
+        e = _residuals(4, 50000, 300.0)
+        assert c.cost_golomb_noalloc(e, 2.0) == oracle.cost_golomb(e, 2.0)
+        quiet = _residuals(5, 40000, 500.0)
+        quiet[12288:16384] = 0                      # the last 4096 samples of segment 0 are silent
+        for st in (0.0, 7.75):
+            want = oracle.cost_golomb(quiet, st)
+            assert c.cost_golomb_noalloc(quiet, st) == want
+            assert c.cost_golomb(quiet, st) == want
+        zeros = np.zeros(3 * 16384 + 100, np.int32)  # all silent, non-zero start state: every guess is 0.0, none is right
+        want = oracle.cost_golomb(zeros, 3.25)
+        assert c.cost_golomb_noalloc(zeros, 3.25) == want and c.cost_golomb(zeros, 3.25) == want
+        # and the next call, smaller and well-behaved, on the scratch those left behind
+        assert c.cost_golomb_noalloc(e[:9000], 0.0) == oracle.cost_golomb(e[:9000], 0.0)
+
+
+def test_no_alloc_refuses_overlapping_calls_on_one_gpu(rsqrt_table):
+    # every context of a GPU shares that GPU's static scratch: a call that finds it in use returns an error, it does not race
+    import threading
+    big = _residuals(6, 1 << 20, 200.0)
+    with sacopt.Context(0, *rsqrt_table) as a, sacopt.Context(0, *rsqrt_table) as b:
+        want = a.cost_golomb(big, 0.0)
+        results, errors = [], []
+
+        def work(c):
+            for _ in range(6):
+                try:
+                    results.append(c.cost_golomb_noalloc(big, 0.0))
+                except sacopt.SacoptError as ex:
+                    errors.append(str(ex))
+
+        ts = [threading.Thread(target=work, args=(c,)) for c in (a, b)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        assert results and all(r == want for r in results)          # whatever ran, ran alone
+        assert all("already running on this GPU" in m for m in errors)
+        assert len(results) + len(errors) == 12
+        assert b.cost_golomb_noalloc(big[:5000], 1.0) == a.cost_golomb(big[:5000], 1.0)
+
+
 def test_no_alloc_matches_cost_golomb(rsqrt_table):
     with sacopt.Context(0, *rsqrt_table) as c:
         big = _residuals(1, 300000, 900.0)     # 19 segments
