@@ -13,5 +13,10 @@ timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pmc_fetch -o fetch 
 timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE -d gpurun_out/pmc_write -o write -- python3 bench.py --steps 1 --warmup 0 --no-extras > /dev/null 2> $O/pmc_w.log
 timeout -s KILL 200 rocprofv3 --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d gpurun_out/pmc_sq -o sq -- python3 bench.py --steps 1 --warmup 0 --no-extras > /dev/null 2> $O/pmc_s.log
 python3 tools/pmc_summary.py $TAG $O > $O/pmc_summary.txt
+# the full-chip regime (what every rank runs at N > 1): one 75-frame call per step
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d gpurun_out/kt75 -o kt -- python3 bench.py --no-extras --frames 75 --steps 2 --warmup 1 > $O/${TAG}_bench_75frames_under_rocprof.json 2> $O/kt75.log
+echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --no-extras --frames 75 --steps 2 --warmup 1   (3 calls of 75 frames x 176400; summarised by tools/prof_summary.py)" > $O/${TAG}_kernel_stats_75frames.txt
+python3 tools/prof_summary.py gpurun_out/kt75/kt_results.db >> $O/${TAG}_kernel_stats_75frames.txt
+rm -rf gpurun_out/kt75
 rm -rf gpurun_out/kt gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_sq
 head -12 $O/${TAG}_kernel_stats.txt | cut -c1-150; cat $O/pmc_summary.txt
