@@ -6,7 +6,9 @@
 #include <stdint.h>
 
 #define LMS_CHUNK 512     // samples staged into the LDS history ring at a time
+#ifndef RSQ_LDS_MAX
 #define RSQ_LDS_MAX 8192  // rsqrt table entries kept in LDS (bits <= 12: Intel needs 10, AMD Zen 12)
+#endif
 // Table entries as 16-bit words: the floats are in [0.5, 2) with the low mantissa byte clear (top byte 0x3F,
 // low byte 0), so bits 8..23 carry everything. sacopt_create checks that every entry fits.
 #define RSQ_PACKABLE(u) ((((u) >> 24) == 0x3Fu) && (((u) & 0xFFu) == 0u))

@@ -561,6 +561,9 @@ __device__ __forceinline__ double spec_exact_sum(uint32_t prods_addr, int (*sJ)[
 // ------------------------------------------------------------------------------------------
 #define L1_SEG 128   // products per segment (32 MFMA steps)
 #define L1_SEGP 130  // segment stride in LDS: the 16 chain lanes of a ds_read_b64 half on 16 different 4-bank groups
+#ifndef S2_CHP
+#define S2_CHP LMS_CHUNK  // two-channel (1280,640) kernel: samples staged per refill
+#endif
 #ifndef S2_DUAL
 #define S2_DUAL 1  // two-channel (1280,640) kernel: two candidate waves per channel with two accumulators each
 #endif
@@ -878,6 +881,196 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
 #pragma unroll
     for (int r = 0; r < R; r++)
       if (valid[r]) { job.state[tap[r]] = w[r]; job.state[R * NT + tap[r]] = eg[r]; }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// LMSADA2(1280,640), both channels of a chain in one workgroup of 512 threads, built so that TWO workgroups share a CU (the
+// kernel of launches with more chains than CUs to give each two, where CU-time is what counts). A sample is a VALU-bound
+// update of all taps followed by serial sections of one or two waves per channel (candidate pass, walk, verification), so a
+// CU that holds one chain idles most of its issue slots; with two resident chains one chain's update runs under the other's
+// serial sections. What it takes: at most 128 VGPRs (four waves per SIMD; the generic k_lms<1280,640,512,8,...> instance
+// has 169: its per-slot index arrays) and at most 80 KB of LDS (it has 93 KB). So, against that instance:
+//   * the history is not a ring: hist[c][k] = x_c(tb - 1280 + k), tb = start of the current block of S2_CH samples; at a block
+//     edge the last 1280 values move down and the next block is loaded. A tap's history value is then at a per-thread base
+//     address that advances by 8 bytes per sample plus a compile-time offset: no index arithmetic per tap;
+//   * slot -> (channel, tap), product address, step size are compile-time functions of the slot number and three per-thread
+//     values; 128-sample blocks (pbuf 2 KB). LDS: table 16 KB + products 33 KB + history 22 KB + 5 KB = 76 KB.
+// Layout as in k_lms<.., SPEC>: half-wave hseg owns segment hseg of BOTH channels (slots 0..3 channel 0, 4..7 channel 1, taps
+// 128 hseg + 32 q + hl), the sixteenth half-wave idles; carried state as k_lms1c (w at [tap], eg at [4096 + tap], tap =
+// channel * 1920 + i), so a chain may change kernels from chunk to chunk. Same arithmetic, same sums: bit-identical results.
+// ------------------------------------------------------------------------------------------
+#define S2_NT 512
+#define S2_CH 128
+#define S2_HL (1280 + S2_CH)
+__global__ __launch_bounds__(S2_NT, 4) void k_lms2(const LmsJob *__restrict__ jobs, const uint16_t *__restrict__ gtab, int bits) {
+  constexpr int S = 1280, T = 1920, NT = S2_NT, CH = S2_CH, HL = S2_HL, R = 8;
+  constexpr int SEG = L1_SEG, SEGP = L1_SEGP, NSEG = 15, TP = 16 * SEGP;
+  __shared__ __attribute__((aligned(256))) uint16_t tab[RSQ_LDS_MAX];
+  __shared__ double prods[2][TP];
+  __shared__ double hist[2][HL];
+  __shared__ double pbuf[2][CH];
+  __shared__ int sJ[2][16][16];
+  __shared__ double sX1[2], predv[2];
+  __shared__ double sA[2][16];
+
+  const LmsJob job = jobs[blockIdx.x];
+  const int tid = threadIdx.x, t0 = job.t0, tend = job.t0 + job.n;
+#ifdef SACOPT_ABLATE
+  const int dbg = bits >> 8;
+#else
+  constexpr int dbg = 0;
+#endif
+  bits &= 0xff;
+  for (int i = tid; i < (2 << bits); i += NT) tab[i] = gtab[i];
+  for (int i = tid; i < 2 * TP; i += NT) (&prods[0][0])[i] = 0.;  // chain 15 of the MFMA passes is idle: keep its operands finite
+
+  const int hseg = tid >> 5, hl = tid & 31, lane = tid & 63, wave = tid >> 6;
+  const bool own = hseg < S / SEG, valid = hseg < NSEG;
+  const int hs = valid ? hseg : NSEG - 1;  // (the idle half-wave reads where segment 14 reads)
+  // history: slot (c, q) reads hist_flat[a_c + tl + 96 - 32 q], tl = t - tb (see above)
+  //   own taps   (i < 1280):  x_c(t - 1 - i)                       = hist[c][tl + 1279 - i]
+  //   other taps (j = i - 1280): c = 0: x_1(t - 1 - j) = hist[1][tl + 1279 - j];  c = 1: x_0(t - j) = hist[0][tl + 1280 - j]
+  const int bi = (own ? 1183 : 2464) - SEG * hs - hl;
+  uint32_t a0 = (uint32_t)(uintptr_t)&hist[0][0] + 8u * (uint32_t)(own ? bi : bi + HL - 1);
+  uint32_t a1 = (uint32_t)(uintptr_t)&hist[0][0] + 8u * (uint32_t)(own ? bi + HL : bi);
+  const uint32_t pa = (uint32_t)(uintptr_t)&prods[0][0] + 8u * (uint32_t)(hseg * SEGP + hl);
+  const double mu = own ? job.mu1 : job.mu2;
+  const int tap0 = SEG * hseg + hl;  // tap of slot (c, q): c * T + tap0 + 32 q
+  double w[R], eg[R];
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    w[r] = 0.; eg[r] = 0.;
+    if (t0 > 0 && job.state && valid) {  // resume: weights / gradient energies of the previous chunk
+      const int tp = (r >> 2) * T + tap0 + 32 * (r & 3);
+      w[r] = job.state[tp];
+      eg[r] = job.state[4096 + tp];
+    }
+  }
+  // history before the chunk comes straight from the stage's input arrays
+  for (int idx = tid; idx < 2 * S; idx += NT) {
+    const int c = idx / S, k = idx - c * S, tau = t0 - S + k;
+    hist[c][k] = (tau >= 0) ? (c ? job.x[1] : job.x[0])[tau] : 0.;
+  }
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);  // the younger wave of a SIMD first (see k_lms1c)
+
+  auto lds_f64 = [](uint32_t addr) { return *(const __attribute__((address_space(3))) double *)(uintptr_t)addr; };
+#ifdef H_PROF  // phase clocks of every wave (tools/s_phases.py): products until the barrier | sum until its barrier | wait there | update
+  long long hp[4] = {0, 0, 0, 0}, hpT = clock64();
+#define S2_TICK(i) { const long long now_ = clock64(); hp[i] += now_ - hpT; hpT = now_; }
+#else
+#define S2_TICK(i)
+#endif
+  for (int t = t0; t < tend; t++) {
+    const int tl = t & (CH - 1);
+    if (tl == 0) {
+      if (t > t0) {
+        // p[k] and val[k+1] = x - p (CalcError, profile.cpp:141-148) of the block that ended, then the history moves down
+        for (int idx = tid; idx < 2 * CH; idx += NT) {
+          const int c = idx / CH, k = idx - c * CH, tau = t - CH + k;
+          const double pv = pbuf[c][k];
+          (c ? job.p[1] : job.p[0])[tau] = pv;
+          double *xo = c ? job.xn[1] : job.xn[0];
+          if (xo) xo[tau] = hist[c][S + k] - pv;
+        }
+        double mv[(2 * S + NT - 1) / NT];
+#pragma unroll
+        for (int u = 0; u < (2 * S + NT - 1) / NT; u++) {
+          const int idx = tid + NT * u;
+          mv[u] = idx < 2 * S ? hist[idx / S][idx % S + CH] : 0.;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < (2 * S + NT - 1) / NT; u++) {
+          const int idx = tid + NT * u;
+          if (idx < 2 * S) hist[idx / S][idx % S] = mv[u];
+        }
+        a0 -= 8u * CH; a1 -= 8u * CH;
+      }
+      for (int idx = tid; idx < 2 * CH; idx += NT) {
+        const int c = idx / CH, k = idx - c * CH, tau = t + k;
+        hist[c][S + k] = (tau < tend) ? (c ? job.x[1] : job.x[0])[tau] : 0.;
+      }
+      __syncthreads();
+    }
+    // ---- products w[i]*hist[i] (nlms.h:111) and the approximate segment sums (tree order: a guess only)
+    double h[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) h[r] = lds_f64((r < 4 ? a0 : a1) + 8u * (uint32_t)(96 - 32 * (r & 3)));  // all reads first
+    double part[2];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      const double pr = w[r] * h[r];
+      *(__attribute__((address_space(3))) double *)(uintptr_t)(pa + 8u * (uint32_t)((r >> 2) * TP + 32 * (r & 3))) = pr;  // (the idle half-wave has slots of its own)
+      if (r & 3) part[r >> 2] += pr; else part[r >> 2] = pr;
+    }
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+      double v = row_prefix16(part[c]);
+      int lo = __double2loint(v), hi = __double2hiint(v);
+      lo = __builtin_amdgcn_update_dpp(0, lo, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1 and 3
+      hi = __builtin_amdgcn_update_dpp(0, hi, 0x142, 0xA, 0xF, false);
+      v += __hiloint2double(hi, lo);
+      if (hl == 31 && valid) sA[c][hseg] = v;
+    }
+    a0 += 8u; a1 += 8u;
+    S2_TICK(0)
+    __syncthreads();
+    // ---- pred = 0.; for i: pred += w[i]*hist[i]  -- strict order: waves 0..3 sum candidates (channel = wave & 1, two groups of
+    // eight per channel), waves 0 and 1 walk and verify
+    {
+      const int sc = wave & 1, grp = wave < 4 ? (wave >> 1) : -1;
+      long long rounds_ = 0;
+      // every lane-derived value of the sum (segment, column, candidate index as a double, operand address) is recomputed per
+      // sample from a lane number the compiler cannot see through: hoisted out of the loop they were spilled (128 VGPRs)
+      int lane_ = lane;
+      asm volatile("" : "+v"(lane_));
+      const double res = spec_exact_sum<NSEG, SEG / 4, SEGP, true>((uint32_t)(uintptr_t)&prods[sc][0], sJ[sc], &sX1[sc], sA[sc], grp, grp == 0, dbg, rounds_, lane_);
+      if (grp == 0 && lane == SPEC_RESULT_LANE(NSEG)) {
+        predv[sc] = res;
+        pbuf[sc][tl] = res;
+      }
+    }
+    S2_TICK(1)
+    __syncthreads();
+    S2_TICK(2)
+    // ---- Update (nlms.h:114-129)
+    const double e0 = hist[0][S + tl] - predv[0];
+    const double e1 = hist[1][S + tl] - predv[1];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      if (!(dbg & 2)) {  // (the idle half-wave updates scratch values of its own -- no exec masks)
+        const double grad = (r < 4 ? e0 : e1) * h[r];
+        eg[r] = 0.95 * eg[r] + (1.0 - 0.95) * (grad * grad);
+        w[r] += (mu * grad * rsq_emul2(eg[r] + 0.001, tab, bits));
+      }
+    }
+    S2_TICK(3)
+  }
+  __syncthreads();
+#ifdef H_PROF
+  if (lane == 0 && tend - t0 >= 64) for (int i = 0; i < 4; i++) pbuf[0][4 * wave + i] = (double)hp[i];  // (flushed below as p[0][tb + ...]: timing builds only)
+  __syncthreads();
+#endif
+  if (tend > t0) {  // the last (possibly short) block
+    const int tb = (tend - 1) & ~(CH - 1);
+    for (int idx = tid; idx < 2 * CH; idx += NT) {
+      const int c = idx / CH, k = idx - c * CH, tau = tb + k;
+      if (tau < tend) {
+        const double pv = pbuf[c][k];
+        (c ? job.p[1] : job.p[0])[tau] = pv;
+        double *xo = c ? job.xn[1] : job.xn[0];
+        if (xo) xo[tau] = hist[c][S + k] - pv;
+      }
+    }
+  }
+  if (job.state && valid) {
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      const int tp = (r >> 2) * T + tap0 + 32 * (r & 3);
+      job.state[tp] = w[r];
+      job.state[4096 + tp] = eg[r];
+    }
   }
 }
 
@@ -2008,7 +2201,8 @@ extern "C" int sacopt_launch_lms(int S, int D, const LmsJob *jobs, int njobs, co
     // 1024 threads are faster for a chain alone (9.4k against 10.0k cycles per sample) but slower in the optimizer's
     // rounds, where the follower stages want room on the same CUs (optimize 571 against 526 ms): A/B switch only
     else if (ABL_SW(bits) & 4096) hipLaunchKernelGGL((k_lms<1280, 640, 1024, 4, 2048, true>), dim3(njobs), dim3(1024), 0, st, jobs, tab, bits);
-    else hipLaunchKernelGGL((k_lms<1280, 640, 512, 8, 2048, true>), dim3(njobs), dim3(512), 0, st, jobs, tab, bits);
+    else if (ABL_SW(bits) & 16384) hipLaunchKernelGGL((k_lms<1280, 640, 512, 8, 2048, true, S2_CHP>), dim3(njobs), dim3(512), 0, st, jobs, tab, bits);
+    else hipLaunchKernelGGL(k_lms2, dim3(njobs), dim3(S2_NT), 0, st, jobs, tab, bits);
   }
   // follower stages: short rings (128 samples per refill) keep their LDS small, so that more of them share a CU and
   // fit beside a lead workgroup (A/B switch 8192: the 512-sample instances)

@@ -61,6 +61,7 @@ struct sacopt_ctx {
   hipStream_t sC = nullptr;                // follower stages of the optimizer rounds
   hipStream_t sE = nullptr;                // optimizer followers behind the first one (may be NULL: all on sC)
   hipStream_t split[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // alternative {st, sB, sC, sD, sE} (see sacopt_create)
+  hipStream_t big[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};    // {st, sB, sC, sD, sE} on every CU: calls with more chains than CUs
   hipStream_t up = nullptr;                // stream of upload() (NULL: st); the full-frame pipeline stages its job tables on sB
   hipStream_t sAall = nullptr;             // lead stage of the full-frame pass when it has more workgroups than sA's reserved CUs
   hipStream_t sD = nullptr;                // final-pass pipeline: stages behind the second LMS stage (may be NULL)
@@ -330,10 +331,21 @@ extern "C" int sacopt_create(int device, const float *rsqrt_tab, int rsqrt_bits,
         std::vector<uint32_t> mall(mr);
         mall[0] = 0xffffffffu;
         masked = hipExtStreamCreateWithCUMask(&c->sAall, words, mall.data()) == hipSuccess;
+        // Third set for large batches (big[]: st, sB, sC, sD, sE on EVERY CU): with more lead workgroups than CUs nothing is
+        // latency-bound any more, the full-frame pass's lead stage runs on sAall, and 32 CUs kept free for it would idle once it
+        // has finished (75 frames: 12 % of the chip from the optimizer's third round on)
+        if (masked) {
+          bool ok = true;
+          for (int i = 0; i < 5 && ok; i++) ok = hipExtStreamCreateWithCUMask(&c->big[i], words, mall.data()) == hipSuccess;
+          if (!ok) {
+            (void)hipGetLastError();
+            for (hipStream_t &p : c->big) if (p) { (void)hipStreamDestroy(p); p = nullptr; }
+          }
+        }
       }
       if (!masked) {
         (void)hipGetLastError();
-        hipStream_t *all[7] = {&c->sA, &c->st, &c->sB, &c->sC, &c->sD, &c->sAall, &c->sE};
+        hipStream_t *all[12] = {&c->sA, &c->st, &c->sB, &c->sC, &c->sD, &c->sAall, &c->sE, &c->big[0], &c->big[1], &c->big[2], &c->big[3], &c->big[4]};
         for (hipStream_t *p : all) if (*p) { (void)hipStreamDestroy(*p); *p = nullptr; }
       }
     }
@@ -392,7 +404,8 @@ extern "C" int sacopt_create(int device, const float *rsqrt_tab, int rsqrt_bits,
 extern "C" void sacopt_destroy(sacopt_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  for (hipStream_t q : {c->st, c->sA, c->sAall, c->sB, c->sC, c->sD, c->sE, c->split[0], c->split[1], c->split[2], c->split[3], c->split[4]})
+  for (hipStream_t q : {c->st, c->sA, c->sAall, c->sB, c->sC, c->sD, c->sE, c->split[0], c->split[1], c->split[2], c->split[3], c->split[4],
+                       c->big[0], c->big[1], c->big[2], c->big[3], c->big[4]})
     if (q) (void)hipStreamSynchronize(q);
   for (hipEvent_t e : c->ev_timed) (void)hipEventDestroy(e);
   for (hipEvent_t e : c->ev_plain) (void)hipEventDestroy(e);
@@ -412,6 +425,7 @@ extern "C" void sacopt_destroy(sacopt_ctx *c) {
   if (c->sAall) (void)hipStreamDestroy(c->sAall);
   if (c->sE) (void)hipStreamDestroy(c->sE);
   for (hipStream_t p : c->split) if (p) (void)hipStreamDestroy(p);
+  for (hipStream_t p : c->big) if (p) (void)hipStreamDestroy(p);
   if (c->st) (void)hipStreamDestroy(c->st);
   delete c;
 }
@@ -497,7 +511,8 @@ static int begin_call(sacopt_ctx *c) {
   HIPCK(c, hipSetDevice(c->device));
   c->err.clear();
   // a call that failed half-way may have left work in flight on the pipeline streams; the arena is about to be reused
-  for (hipStream_t s : {c->st, c->sA, c->sAall, c->sB, c->sC, c->sD, c->sE, c->split[0], c->split[1], c->split[2], c->split[3], c->split[4]})
+  for (hipStream_t s : {c->st, c->sA, c->sAall, c->sB, c->sC, c->sD, c->sE, c->split[0], c->split[1], c->split[2], c->split[3], c->split[4],
+                       c->big[0], c->big[1], c->big[2], c->big[3], c->big[4]})
     if (s) HIPCK(c, hipStreamSynchronize(s));
   // nothing is in flight any more: the staging memory of the previous call can be reused (several blocks -> one of their size)
   if (c->pins.size() > 1) {
@@ -530,6 +545,24 @@ static int end_timing(sacopt_ctx *c) {
   c->lms_launches = (int)c->lms_ev.size();
   return 0;
 }
+
+// Swaps {st, sB, sC, sD, sE} for another stream set (sacopt_create: split[] / big[]) for the duration of a call.
+struct StreamSetGuard {
+  sacopt_ctx *c;
+  hipStream_t keep[5];
+  bool on;
+  StreamSetGuard(sacopt_ctx *ctx, hipStream_t *set) : c(ctx), keep{ctx->st, ctx->sB, ctx->sC, ctx->sD, ctx->sE}, on(set && set[0]) {
+    if (on) { c->st = set[0]; c->sB = set[1]; c->sC = set[2]; c->sD = set[3]; c->sE = set[4]; }
+  }
+  ~StreamSetGuard() { if (on) { c->st = keep[0]; c->sB = keep[1]; c->sC = keep[2]; c->sD = keep[3]; c->sE = keep[4]; } }
+};
+// Calls whose full-frame pass has more lead workgroups than the 32 CUs reserved for it run that stage on sAall anyway: from
+// there on nothing is gained by keeping the other streams off those CUs (75 frames: 1350 -> 1291 ms; but 24 / 30 frames, whose
+// full-frame lead stage still sits on the reserved CUs and bounds the call: 667 -> 722, 710 -> 787 ms with full masks).
+// Window evaluations without a full-frame pass (Optimize, GetCost) take the full masks as soon as a round has more chains than CUs.
+#ifndef BIG_FRAMES
+#define BIG_FRAMES 32
+#endif
 
 // A frame window staged on the device
 struct DevFrame {
@@ -1226,6 +1259,7 @@ extern "C" int sacopt_predict_stereo_frames(sacopt_ctx *c, int profile, int nfra
             ((out[f].map0 || out[f].map1) ? map_bytes(nn > 0 ? nn : 0) : 0);
   }
   if (arena_reserve(c, need)) return 1;
+  StreamSetGuard set_guard(c, nframes > BIG_FRAMES ? c->big : nullptr);
   HIPCK(c, hipEventRecord(c->ev0, c->st));
   std::vector<DevFrame> fr;
   if (stage_frames(c, nframes, frames, from, n, fr)) return 1;
@@ -1367,6 +1401,7 @@ extern "C" int sacopt_get_costs(sacopt_ctx *c, int profile, int nframes, const s
     need += 2 * bitplane_cost_bytes(2 * (size_t)nframes * ncand, mxn, 32);
   }
   if (arena_reserve(c, need)) return 1;
+  StreamSetGuard set_guard(c, (long long)nframes * ncand > 256 ? c->big : nullptr);
   HIPCK(c, hipEventRecord(c->ev0, c->st));
   std::vector<DevFrame> fr;
   if (stage_frames(c, nframes, frames, from, n, fr)) return 1;
@@ -1537,6 +1572,7 @@ extern "C" int sacopt_optimize_frames(sacopt_ctx *c, int profile, int nframes, c
     need += (size_t)(ncoef_loop + 1) * bitplane_cost_bytes(2 * (size_t)nframes * 13, mxn, 32)  /* <= 12 candidates + the baseline per round */;
   }
   if (arena_reserve(c, need)) return 1;
+  StreamSetGuard set_guard(c, (long long)nframes * 11 > 256 ? c->big : nullptr);
   HIPCK(c, hipEventRecord(c->ev0, c->st));
   std::vector<DevFrame> fr;
   if (stage_frames(c, nframes, frames, from.data(), wn.data(), fr)) return 1;
@@ -1579,19 +1615,13 @@ extern "C" int sacopt_encode_frames(sacopt_ctx *c, int profile, int nframes, con
     need += (size_t)(ncoef_loop + 1) * bitplane_cost_bytes(2 * (size_t)nframes * 13, mxn, 32)  /* <= 12 candidates + the baseline per round */;
   }
   if (arena_reserve(c, need)) return 1;
-  // small batches: the stream set that keeps the full-frame followers off the optimizer's CUs (see sacopt_create)
-  struct SetGuard {
-    sacopt_ctx *c; hipStream_t keep[5]; bool on;
-    ~SetGuard() { if (on) { c->st = keep[0]; c->sB = keep[1]; c->sC = keep[2]; c->sD = keep[3]; c->sE = keep[4]; } }
-  } set_guard{c, {c->st, c->sB, c->sC, c->sD, c->sE}, false};
+  // small batches: the stream set that keeps the full-frame followers off the optimizer's CUs; large ones: every stream on
+  // every CU (see sacopt_create)
   bool use_split = c->split[0] && ncoef_loop > 0 && nframes <= 16 && pd.nlms == 4;
 #ifdef SACOPT_ABLATE
   if (getenv("SACOPT_NOSPLIT")) use_split = false;
 #endif
-  if (use_split) {
-    set_guard.on = true;
-    c->st = c->split[0]; c->sB = c->split[1]; c->sC = c->split[2]; c->sD = c->split[3]; c->sE = c->split[4];
-  }
+  StreamSetGuard set_guard(c, use_split ? c->split : (nframes > BIG_FRAMES ? c->big : nullptr));
   HIPCK(c, hipEventRecord(c->ev0, c->st));
   std::vector<DevFrame> fr;
   if (stage_frames(c, nframes, frames, nullptr, nullptr, fr)) return 1;
@@ -1856,17 +1886,20 @@ extern "C" int sacopt_lms_pair(sacopt_ctx *c, int S, int D, double mu1, double m
   j.p[1] = arena_alloc<double>(c, n);
   j.mu1 = mu1; j.mu2 = mu2; j.n = n; j.t0 = 0; j.state = nullptr;
   std::vector<LmsJob> jobs = {j};
+  int sw = 0;
+#ifdef SACOPT_ABLATE
+  if (const char *dbg = getenv("SACOPT_DBG")) sw = atoi(dbg) << 8;
+  // timing builds: the same job SACOPT_REPL times in one launch (every copy writes the same values to the same outputs), to time a
+  // chain -- and read its phase clocks -- while the chip is full
+  if (const char *rp = getenv("SACOPT_REPL")) jobs.assign(atoi(rp) > 0 ? atoi(rp) : 1, j);
+#endif
   LmsJob *dj;
   if (upload(c, jobs, &dj)) return 1;
   hipEvent_t a, b;
   TAKE_EVENT(c, a, true);
   TAKE_EVENT(c, b, true);
   HIPCK(c, hipEventRecord(a, c->st));
-  int sw = 0;
-#ifdef SACOPT_ABLATE
-  if (const char *dbg = getenv("SACOPT_DBG")) sw = atoi(dbg) << 8;
-#endif
-  if (sacopt_launch_lms(S, D, dj, 1, c->d_tab, c->bits | sw, c->st, L1C_FRAMES)) { c->err = "unsupported (S,D) or launch failure"; return 1; }
+  if (sacopt_launch_lms(S, D, dj, (int)jobs.size(), c->d_tab, c->bits | sw, c->st, L1C_FRAMES)) { c->err = "unsupported (S,D) or launch failure"; return 1; }
   HIPCK(c, hipEventRecord(b, c->st));
   c->lms_ev.push_back({a, b});
   if (copy_out(c, p0, j.p[0], (size_t)n * 8) || copy_out(c, p1, j.p[1], (size_t)n * 8)) return 1;

@@ -8,9 +8,18 @@
 #include <vector>
 #include <algorithm>
 struct Rec { unsigned hwid, xcc; unsigned long long t0, t1; };
+// VG: highest VGPR the kernel is made to allocate (a clobber), so that the probe has the register footprint of the kernel in question
+template <int VG>
 __global__ void probe(Rec *out, int lds_bytes, unsigned long long ticks) {
   extern __shared__ double lds[];
   if (lds_bytes == -1) lds[threadIdx.x] = 0.;
+  if (lds_bytes == -2) {  // (never true: forces a private segment -- scratch -- when ticks' top bit asks for it at compile time)
+    volatile int spill[16];
+    for (int i = 0; i < 16; i++) spill[i] = i * (int)ticks;
+    lds[threadIdx.x] = spill[threadIdx.x & 15];
+  }
+  if (VG == 127) asm volatile("v_mov_b32 v127, 0" ::: "v127");
+  if (VG == 168) asm volatile("v_mov_b32 v168, 0" ::: "v168");
   const unsigned long long t0 = wall_clock64();
   while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
   if (threadIdx.x == 0) {
@@ -22,12 +31,15 @@ __global__ void probe(Rec *out, int lds_bytes, unsigned long long ticks) {
   }
 }
 int main(int argc, char **argv) {
-  const int ng = argc > 1 ? atoi(argv[1]) : 512, kb = argc > 2 ? atoi(argv[2]) : 60, nt = argc > 3 ? atoi(argv[3]) : 1024;
+  const int ng = argc > 1 ? atoi(argv[1]) : 512, kb = argc > 2 ? atoi(argv[2]) : 60, nt = argc > 3 ? atoi(argv[3]) : 1024, vg = argc > 4 ? atoi(argv[4]) : 0;
+  auto kern = vg == 127 ? probe<127> : vg == 168 ? probe<168> : probe<0>;
   Rec *d; hipMalloc(&d, ng * sizeof(Rec));
-  hipFuncSetAttribute((const void *)probe, hipFuncAttributeMaxDynamicSharedMemorySize, kb * 1024);
+  hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kb * 1024);
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  hipLaunchKernelGGL(kern, dim3(ng), dim3(nt), kb * 1024, 0, d, kb * 1024, 20000ull);  // warm-up (scratch set-up, code upload)
+  hipDeviceSynchronize();
   hipEventRecord(a);
-  hipLaunchKernelGGL(probe, dim3(ng), dim3(nt), kb * 1024, 0, d, kb * 1024, 20000ull);  // 200 us at 100 MHz
+  hipLaunchKernelGGL(kern, dim3(ng), dim3(nt), kb * 1024, 0, d, kb * 1024, 20000ull);  // 200 us at 100 MHz
   hipEventRecord(b);
   if (hipDeviceSynchronize() != hipSuccess) { printf("launch failed\n"); return 1; }
   float ms; hipEventElapsedTime(&ms, a, b);
@@ -39,7 +51,7 @@ int main(int argc, char **argv) {
     auto &v = kv.second; std::sort(v.begin(), v.end());
     for (size_t i = 1; i < v.size(); i++) if (v[i].first < v[i - 1].second) overl++;
   }
-  printf("%d workgroups x %d threads, %d KB LDS: %.3f ms (one spin = 0.200 ms), %zu distinct CUs, %d overlapping pairs on a CU\n", ng, nt, kb, ms,
+  printf("%d workgroups x %d threads, %d KB LDS, VGPR clobber %d: %.3f ms (one spin = 0.200 ms), %zu distinct CUs, %d overlapping pairs on a CU\n", ng, nt, kb, vg, ms,
          cu.size(), overl);
   return 0;
 }

@@ -16,7 +16,7 @@ for n, i in enumerate(fins):
         while k > 0 and seg[k][1] - seg[k - 1][2] < 20e6: k -= 1
         seg = seg[k:]
     t0 = seg[0][1]; t1 = seg[-1][2]
-    lead = [r for r in seg if "k_lms<1280" in r[0] or "k_lms1c" in r[0]]
+    lead = [r for r in seg if "k_lms<1280" in r[0] or "k_lms1c" in r[0] or "k_lms2" in r[0]]
     h2 = [r for r in seg if "k_lms<256" in r[0]]
     print(f"round {n}: {(t1 - t0) / 1e6:7.1f} ms  kernels {len(seg):4d}  lead launches {len(lead):3d} busy {sum(r[2]-r[1] for r in lead)/1e6:7.1f} ms"
           f"  (256,128) launches {len(h2):3d} busy {sum(r[2]-r[1] for r in h2)/1e6:7.1f} ms   gap before {(t0 - prev_end) / 1e6:5.2f} ms")
