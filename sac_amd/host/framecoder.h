@@ -15,7 +15,8 @@
 // frame is predicted with the parameters Optimize selected (the reference codes with baseprofile, :459) --
 // such frames go into a stream whose header carries SAC_PROFILE_PARAMS (sacfile.h): ToRecord / FromRecord move the
 // parameters between a FrameCoder and a FrameRecord.
-// Header-only; link with libsacopt.so. Not thread-safe (like the reference).
+// Header-only; link with libsacopt.so. A FrameCoder is not thread-safe (like the reference); different contexts may be driven
+// from different threads (sharder.h).
 #ifndef SACOPT_FRAMECODER_H
 #define SACOPT_FRAMECODER_H
 #include <cstdint>
@@ -61,8 +62,12 @@ class FrameCoder {
 
   // Predict() for a batch of frames (same profile type) in one call; frames are independent (codec.cpp:156-159).
   static void PredictBatch(FrameCoder *const *fc, int nframes, bool optimize, bool apply = false) {
+    if (nframes > 0) PredictBatchOn(fc[0]->ctx_, fc, nframes, optimize, apply);
+  }
+  // ... on a given context (the multi-GPU sharder of sharder.h hands each context its own range of frames)
+  static void PredictBatchOn(sacopt_ctx *ctx, FrameCoder *const *fc, int nframes, bool optimize, bool apply = false) {
     if (nframes <= 0) return;
-    if (apply) { PredictBatchApply(fc, nframes); return; }
+    if (apply) { PredictBatchApply(ctx, fc, nframes); return; }
     FrameCoder &f0 = *fc[0];
     const int ncoef = (int)f0.baseprofile.coefs.size();
     std::vector<sacopt_frame> fr(nframes);
@@ -78,7 +83,7 @@ class FrameCoder {
       out[b].s2u0 = f.s2u_error[0].data(); out[b].s2u1 = f.s2u_error[1].data();
       out[b].map0 = f.s2u_error_map[0].data(); out[b].map1 = f.s2u_error_map[1].data();
     }
-    f0.check(sacopt_encode_frames(f0.ctx_, f0.baseprofile.type, nframes, fr.data(), prof.data(), optimize ? ncoef : 0, best.data(), out.data()));
+    check_on(ctx, sacopt_encode_frames(ctx, f0.baseprofile.type, nframes, fr.data(), prof.data(), optimize ? ncoef : 0, best.data(), out.data()));
     for (int b = 0; b < nframes; b++) {
       FrameCoder &f = *fc[b];
       f.maxbpn[0] = out[b].maxbpn[0]; f.maxbpn[1] = out[b].maxbpn[1];
@@ -91,7 +96,7 @@ class FrameCoder {
   }
 
   // Optimize, then PredictStereoFrame(optprofile, 0, 1, 0, numsamples): two library calls, the second needs the first's result
-  static void PredictBatchApply(FrameCoder *const *fc, int nframes) {
+  static void PredictBatchApply(sacopt_ctx *ctx, FrameCoder *const *fc, int nframes) {
     FrameCoder &f0 = *fc[0];
     const int ncoef = (int)f0.baseprofile.coefs.size();
     std::vector<sacopt_frame> fr(nframes);
@@ -107,8 +112,8 @@ class FrameCoder {
       out[b].s2u0 = f.s2u_error[0].data(); out[b].s2u1 = f.s2u_error[1].data();
       out[b].map0 = f.s2u_error_map[0].data(); out[b].map1 = f.s2u_error_map[1].data();
     }
-    f0.check(sacopt_optimize_frames(f0.ctx_, f0.baseprofile.type, nframes, fr.data(), prof.data(), ncoef, best.data(), nullptr, 0, nullptr));
-    f0.check(sacopt_predict_stereo_frames(f0.ctx_, f0.baseprofile.type, nframes, fr.data(), nullptr, nullptr, best.data(), out.data()));
+    check_on(ctx, sacopt_optimize_frames(ctx, f0.baseprofile.type, nframes, fr.data(), prof.data(), ncoef, best.data(), nullptr, 0, nullptr));
+    check_on(ctx, sacopt_predict_stereo_frames(ctx, f0.baseprofile.type, nframes, fr.data(), nullptr, nullptr, best.data(), out.data()));
     for (int b = 0; b < nframes; b++) {
       FrameCoder &f = *fc[b];
       f.maxbpn[0] = out[b].maxbpn[0]; f.maxbpn[1] = out[b].maxbpn[1];
@@ -194,6 +199,9 @@ class FrameCoder {
   }
   // with_optprofile: decode with each frame's optprofile (streams that carry optimised parameters)
   static void UnpredictBatch(FrameCoder *const *fc, int nframes, bool with_optprofile = false) {
+    if (nframes > 0) UnpredictBatchOn(fc[0]->ctx_, fc, nframes, with_optprofile);
+  }
+  static void UnpredictBatchOn(sacopt_ctx *ctx, FrameCoder *const *fc, int nframes, bool with_optprofile = false) {
     if (nframes <= 0) return;
     FrameCoder &f0 = *fc[0];
     const int ncoef = (int)f0.baseprofile.coefs.size();
@@ -206,7 +214,7 @@ class FrameCoder {
       const SacProfile &p = with_optprofile ? f.optprofile : f.baseprofile;
       for (int i = 0; i < ncoef; i++) c[(size_t)b * ncoef + i] = p.coefs[i].vdef;
     }
-    f0.check(sacopt_unpredict_stereo_frames(f0.ctx_, f0.baseprofile.type, nframes, d.data(), c.data()));
+    check_on(ctx, sacopt_unpredict_stereo_frames(ctx, f0.baseprofile.type, nframes, d.data(), c.data()));
   }
 
   std::vector<std::vector<int32_t>> samples, error, s2u_error, s2u_error_map;
@@ -228,7 +236,8 @@ class FrameCoder {
     }
     return d;
   }
-  void check(int rc) { if (rc) throw std::runtime_error(std::string("sacopt: ") + sacopt_last_error(ctx_)); }
+  void check(int rc) { check_on(ctx_, rc); }
+  static void check_on(sacopt_ctx *ctx, int rc) { if (rc) throw std::runtime_error(std::string("sacopt: ") + sacopt_last_error(ctx)); }
   sacopt_ctx *ctx_;
   int numchannels, framesize, numsamples = 0;
   double cost_state = 0.;

@@ -1,8 +1,10 @@
 // Host-side example / test driver: encodes synthetic frames through sacopt::FrameCoder (the C++ mirror of the
 // reference's FrameCoder on this path) and prints, per frame, the selected parameters and checksums of the
 // residual arrays. tests/test_gpu_parity.py::test_cpp_host_framecoder compares the output with the ctypes path.
-//   usage: host_example <profile> <nframes> <numsamples> <optimize 0|1|2>     (2: also the "apply" round trip -- frames coded with
-//          the parameters Optimize selected travel through the parameter-extension stream records of sacfile.h and decode back)
+//   usage: host_example <profile> <nframes> <numsamples> <optimize 0|1|2> [nctx]   (2: also the "apply" round trip -- frames coded
+//          with the parameters Optimize selected travel through the parameter-extension stream records of sacfile.h and decode back;
+//          nctx > 1: that many contexts, on the node's GPUs round robin, driven by sharder.h's EncodeFrames / DecodeFrames -- one host
+//          thread and one contiguous range of frames per context)
 #include <algorithm>
 #include <cinttypes>
 #include <cstdio>
@@ -11,6 +13,7 @@
 #include <memory>
 
 #include "framecoder.h"
+#include "sharder.h"
 
 // integer-deterministic stereo test signal (same generator family as sac_amd/synth.py is NOT needed here:
 // the test reads the samples back through the checksum of the inputs as well)
@@ -35,8 +38,18 @@ static uint64_t fnv(const int32_t *p, int n) {
 int main(int argc, char **argv) {
   if (argc < 5) { fprintf(stderr, "usage: %s profile nframes numsamples optimize\n", argv[0]); return 2; }
   const int profile = atoi(argv[1]), nframes = atoi(argv[2]), n = atoi(argv[3]), optimize = atoi(argv[4]);
-  sacopt_ctx *ctx = nullptr;
-  if (sacopt_create(0, nullptr, 0, &ctx)) { fprintf(stderr, "sacopt_create: %s\n", sacopt_last_error(nullptr)); return 1; }
+  const int nctx = argc > 5 ? std::max(1, atoi(argv[5])) : 1;
+  int ndev = 1;
+  if (const char *e = getenv("HOST_EXAMPLE_GPUS")) ndev = std::max(1, atoi(e));  // GPUs to spread the contexts over (default: all on GPU 0)
+  std::vector<sacopt_ctx *> ctxs((size_t)nctx, nullptr);
+  for (int i = 0; i < nctx; i++)
+    if (sacopt_create(i % ndev, nullptr, 0, &ctxs[i])) {
+      fprintf(stderr, "sacopt_create: %s\n", sacopt_last_error(nullptr));
+      for (sacopt_ctx *c : ctxs) sacopt_destroy(c);
+      return 1;
+    }
+  sacopt_ctx *ctx = ctxs[0];
+  auto destroy_all = [&] { for (sacopt_ctx *c : ctxs) sacopt_destroy(c); };
   try {
     std::vector<std::unique_ptr<sacopt::FrameCoder>> fc;
     std::vector<sacopt::FrameCoder *> ptr;
@@ -46,7 +59,8 @@ int main(int argc, char **argv) {
       fc[b]->SetNumSamples(n);
       ptr.push_back(fc[b].get());
     }
-    sacopt::FrameCoder::PredictBatch(ptr.data(), nframes, optimize != 0);
+    if (nctx > 1) sacopt::EncodeFrames(ctxs.data(), nctx, ptr.data(), nframes, optimize != 0);
+    else sacopt::FrameCoder::PredictBatch(ptr.data(), nframes, optimize != 0);
     // decoder round trip (FrameCoder::Unpredict, codec.cpp:463-478): channel 0 from its plain residuals, channel 1 as a
     // mapped channel (U2S of s2u_error_map, utils.h:62-66, with the Remap tables of the frame); samples are overwritten
     std::vector<std::vector<int32_t>> keep0(nframes), keep1(nframes), keepe1(nframes);
@@ -59,7 +73,8 @@ int main(int argc, char **argv) {
       std::fill(f.samples[0].begin(), f.samples[0].end(), 0);
       std::fill(f.samples[1].begin(), f.samples[1].end(), 0);
     }
-    sacopt::FrameCoder::UnpredictBatch(ptr.data(), nframes);
+    if (nctx > 1) sacopt::DecodeFrames(ctxs.data(), nctx, ptr.data(), nframes);
+    else sacopt::FrameCoder::UnpredictBatch(ptr.data(), nframes);
     std::vector<int> dec_ok(nframes);
     for (int b = 0; b < nframes; b++) {
       sacopt::FrameCoder &f = *fc[b];
@@ -76,7 +91,8 @@ int main(int argc, char **argv) {
         ac[b]->SetNumSamples(n);
         ap.push_back(ac[b].get());
       }
-      sacopt::FrameCoder::PredictBatch(ap.data(), nframes, true, true);
+      if (nctx > 1) sacopt::EncodeFrames(ctxs.data(), nctx, ap.data(), nframes, true, true);
+      else sacopt::FrameCoder::PredictBatch(ap.data(), nframes, true, true);
       // stream: header with the flag, one record per frame; the payload stands in for the host's entropy coder (raw residuals)
       std::vector<uint8_t> stream;
       sacopt::SacHeader h;
@@ -107,7 +123,8 @@ int main(int argc, char **argv) {
         dp.push_back(dc[b].get());
       }
       if (apply_ok) {
-        sacopt::FrameCoder::UnpredictBatch(dp.data(), nframes, true);
+        if (nctx > 1) sacopt::DecodeFrames(ctxs.data(), nctx, dp.data(), nframes, true);
+        else sacopt::FrameCoder::UnpredictBatch(dp.data(), nframes, true);
         for (int b = 0; b < nframes; b++)
           apply_ok = apply_ok && dc[b]->samples[0] == fc[b]->samples[0] && dc[b]->samples[1] == fc[b]->samples[1] && pos == stream.size();
       }
@@ -126,9 +143,9 @@ int main(int argc, char **argv) {
     }
   } catch (const std::exception &e) {
     fprintf(stderr, "%s\n", e.what());
-    sacopt_destroy(ctx);
+    destroy_all();
     return 1;
   }
-  sacopt_destroy(ctx);
+  destroy_all();
   return 0;
 }

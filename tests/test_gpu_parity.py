@@ -424,6 +424,23 @@ def test_cpp_host_framecoder():
         assert ln[30:32] == ["apply", "ok"]   # frames coded with the SELECTED parameters, carried by sacfile.h's extension records, decode back
 
 
+def test_cpp_host_sharder_two_contexts_two_threads():
+    # sac_amd/host/sharder.h (the Codec::EncodeFile loop, codec.cpp:543-555, over several contexts): two and three contexts
+    # on GPU 0, one host thread each, contiguous frame ranges, running CONCURRENTLY -- every line (input / residual / map
+    # checksums, maxbpn, selected parameters, decoder and parameter-stream round trips) must equal the one-context run's
+    import os, subprocess
+    exe = os.path.join(os.path.dirname(sacopt.LIB_PATH), "host", "host_example")
+    if not os.path.exists(exe):
+        pytest.skip("host_example not built")
+    runs = {}
+    for nctx in (1, 2, 3):
+        out = subprocess.run([exe, "2", "5", "2600", "2", str(nctx)], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr
+        runs[nctx] = out.stdout.strip().splitlines()
+    assert len(runs[1]) == 5 and all(ln.endswith("decode ok apply ok") for ln in runs[1])
+    assert runs[2] == runs[1] and runs[3] == runs[1]
+
+
 # ---------------------------------------------------------------- BASELINE sizes (176400-sample frames)
 def test_full_size_frames_properties(ctx, oracle):
     # Size-independent properties at the benchmark's frame size (4 s @ 44.1 kHz):
