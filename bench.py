@@ -387,10 +387,15 @@ def main():
                 except Exception as e:
                     measured = {"error": str(e)[:200]}
                 line["end_to_end"] = {"cores": cores, "gpu_step_s": gpu_s, "host_coder_s": coder_s, "host_coder_parallel": measured,
-                                      "serial_samples_per_s": nfr * FRAME / (gpu_s + coder_s),
-                                      "pipelined_samples_per_s": nfr * FRAME / max(gpu_s, coder_s),
+                                      "serial_samples_per_s_derived": nfr * FRAME / (gpu_s + coder_s),
                                       "note": "host coder = the reference's FrameCoder::Encode() (bit-plane + range coder, unchanged, on the host); "
                                               "its time is " + how}
+                try:  # MEASURED end to end: the reference's own program with the batched, pipelined binding (tools/e2e_pipeline.py, own process)
+                    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "e2e_pipeline.py"), str(cores), "15"],
+                                         capture_output=True, text=True, timeout=400)
+                    line["end_to_end"]["measured"] = json.loads(out.stdout.strip().splitlines()[-1])
+                except Exception as e:
+                    line["end_to_end"]["measured"] = {"error": str(e)[:200]}
         if world == 1 and nfr == NFRAMES and not args.no_extras:
             line["split"] = split_extra(ctx, torch, sacopt, b)
             line["apply_selected_parameters"] = apply_params_extra(ctx, torch, sacopt, b, nfr)

@@ -10,6 +10,15 @@
 // these strong definitions win at link time; nothing in the reference's sources is edited.
 // `oracle/_ref/sac_gpu --encode --normal in.wav out.sac` must write the file `oracle/_ref/sac` writes
 // (tests/test_gpu_stream.py::test_reference_program_with_gpu_predictor).
+//
+// The batched binding of INTEGRATION.md as well: with SAC_GPU_BATCH=B (> 1) a third member is replaced,
+//   Codec::EncodeFile()      src/codec.cpp:530-556   -> the same loop over batches of B frames: ONE sacopt_encode_frames call per
+//                                                       batch; the frames' Encode() -- the reference's own bit-plane / range
+//                                                       coder, both variants per channel (codec.cpp:268-280, 469-472) -- runs on
+//                                                       SAC_GPU_CODER_THREADS host threads WHILE the GPU works on the next batch
+//                                                       (frames are independent: codec.cpp:156-159, 240-242); WriteEncoded in
+//                                                       frame order. The file must still be the reference's, byte for byte.
+// It prints one line "sac_gpu_timing {...}" to stderr: wall time of the loop, of the GPU calls and of the coder.
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -22,7 +31,9 @@
 #include <iostream>
 #include <random>
 #include <sstream>
+#include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #define private public
@@ -84,4 +95,120 @@ void FrameCoder::Unpredict() {
     std::cerr << "sacopt_unpredict_stereo_frames: " << sacopt_last_error(gpu()) << std::endl;
     exit(2);
   }
+}
+
+// ---- Codec::EncodeFile (src/codec.cpp:530-556), batched and pipelined when SAC_GPU_BATCH > 1 -----------------------------
+static void predict_batch(std::vector<std::unique_ptr<FrameCoder>> &fc, int nb, bool optimize) {
+  if (!nb) return;
+  std::vector<sacopt_frame> fr(nb);
+  std::vector<sacopt_residuals> out(nb);
+  const SacProfile &bp = fc[0]->baseprofile;
+  std::vector<double> prof, best((size_t)nb * bp.coefs.size());
+  for (auto &k : bp.coefs) { prof.push_back(k.vmin); prof.push_back(k.vmax); prof.push_back(k.vdef); }
+  for (int b = 0; b < nb; b++) {
+    FrameCoder &f = *fc[b];
+    for (int ch = 0; ch < f.numchannels; ch++) {  // the MapEncoder needs the host tables (codec.cpp:448-452, :258)
+      f.framestats[ch].mymap.Reset();
+      f.framestats[ch].mymap.Analyse(&(f.samples[ch][0]), f.numsamples);
+    }
+    fr[b] = {&f.samples[0][0], &f.samples[1][0], f.numsamples};
+    out[b] = sacopt_residuals();
+    out[b].err0 = &f.error[0][0]; out[b].err1 = &f.error[1][0];
+    out[b].s2u0 = &f.s2u_error[0][0]; out[b].s2u1 = &f.s2u_error[1][0];
+    out[b].map0 = &f.s2u_error_map[0][0]; out[b].map1 = &f.s2u_error_map[1][0];
+  }
+  if (sacopt_encode_frames(gpu(), bp.type, nb, fr.data(), prof.data(), optimize ? (int)bp.coefs.size() : 0, best.data(), out.data())) {
+    std::cerr << "sacopt_encode_frames: " << sacopt_last_error(gpu()) << std::endl;
+    exit(2);
+  }
+  for (int b = 0; b < nb; b++) {
+    FrameCoder &f = *fc[b];
+    f.framestats[0].maxbpn = out[b].maxbpn[0]; f.framestats[1].maxbpn = out[b].maxbpn[1];          // codec.cpp:207-208
+    f.framestats[0].maxbpn_map = out[b].maxbpn[2]; f.framestats[1].maxbpn_map = out[b].maxbpn[3];  // codec.cpp:210-211
+  }
+}
+
+void Codec::EncodeFile(Wav &myWav, Sac &mySac, int profile) {
+  const int numchannels = myWav.getNumChannels();
+  framesize = 4 * myWav.getSampleRate();
+  const int B = std::max(1, getenv("SAC_GPU_BATCH") ? atoi(getenv("SAC_GPU_BATCH")) : 1);
+  const int T = std::max(1, getenv("SAC_GPU_CODER_THREADS") ? atoi(getenv("SAC_GPU_CODER_THREADS")) : 16);
+  mySac.SetProfile(profile);
+  mySac.WriteHeader(myWav);
+  myWav.InitFileBuf(framesize);
+  int samplescoded = 0, samplestocode = myWav.getNumSamples();
+  if (B == 1 || numchannels != 2) {  // the reference's loop as it stands (its Predict is the one above)
+    FrameCoder myFrame(numchannels, framesize, profile);
+    while (samplestocode > 0) {
+      int samplesread = myWav.ReadSamples(myFrame.samples, framesize);
+      myFrame.SetNumSamples(samplesread);
+      myFrame.Predict();
+      myFrame.Encode();
+      myFrame.WriteEncoded(mySac);
+      samplescoded += samplesread;
+      PrintProgress(samplescoded, myWav.getNumSamples());
+      samplestocode -= samplesread;
+    }
+    std::cout << std::endl;
+    return;
+  }
+  using clk = std::chrono::steady_clock;
+  auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+  gpu();  // context creation (rsqrtss probe, streams) is not part of the loop's time
+  const bool optimize = getenv("SAC_GPU_OPTIMIZE") != nullptr;
+  std::vector<std::unique_ptr<FrameCoder>> set[2];
+  for (auto &s : set) for (int b = 0; b < B; b++) s.emplace_back(new FrameCoder(numchannels, framesize, profile));
+  int nb[2] = {0, 0};
+  std::vector<std::thread> coders;           // coding the batch in set[cur ^ 1] while the GPU works on set[cur]
+  std::vector<double> coder_busy((size_t)T, 0.);
+  double gpu_s = 0., coder_crit_s = 0.;
+  int batches = 0;
+  const auto t_begin = clk::now();
+  auto start_coding = [&](int which) {
+    coders.clear();
+    for (int t = 0; t < T && t < nb[which]; t++)
+      coders.emplace_back([&, t, which] {
+        const auto a = clk::now();
+        for (int b = t; b < nb[which]; b += T) set[which][b]->Encode();  // codec.cpp:469-472, unchanged
+        coder_busy[(size_t)t] = secs(a, clk::now());
+      });
+  };
+  auto finish_coding = [&](int which) {  // join, then the records in frame order
+    for (auto &th : coders) th.join();
+    double mx = 0.;
+    for (size_t t = 0; t < coders.size(); t++) mx = std::max(mx, coder_busy[t]);
+    coder_crit_s += mx;
+    coders.clear();
+    for (int b = 0; b < nb[which]; b++) {
+      set[which][b]->WriteEncoded(mySac);
+      samplescoded += set[which][b]->GetNumSamples();
+    }
+    PrintProgress(samplescoded, myWav.getNumSamples());
+  };
+  int cur = 0;
+  bool pending = false;  // a batch is being coded in set[cur ^ 1]
+  while (samplestocode > 0) {
+    nb[cur] = 0;
+    while (nb[cur] < B && samplestocode > 0) {
+      FrameCoder &f = *set[cur][nb[cur]];
+      const int samplesread = myWav.ReadSamples(f.samples, framesize);
+      f.SetNumSamples(samplesread);
+      samplestocode -= samplesread;
+      nb[cur]++;
+    }
+    const auto a = clk::now();
+    predict_batch(set[cur], nb[cur], optimize);  // GPU (blocking); the coder threads of the previous batch run meanwhile
+    gpu_s += secs(a, clk::now());
+    batches++;
+    if (pending) finish_coding(cur ^ 1);
+    start_coding(cur);
+    pending = true;
+    cur ^= 1;
+  }
+  if (pending) finish_coding(cur ^ 1);
+  std::cout << std::endl;
+  const double total = secs(t_begin, clk::now());
+  std::cerr << "sac_gpu_timing {\"samples\": " << myWav.getNumSamples() << ", \"batch_frames\": " << B << ", \"batches\": " << batches
+            << ", \"coder_threads\": " << T << ", \"optimize\": " << (optimize ? 1 : 0) << ", \"loop_s\": " << total << ", \"gpu_calls_s\": " << gpu_s
+            << ", \"coder_critical_path_s\": " << coder_crit_s << "}" << std::endl;
 }

@@ -276,6 +276,15 @@ def test_reference_program_with_gpu_predictor(tmp_path, prof, flag):
     if prof == 2:   # Optimize indexes 8 coefficients (codec.cpp:389): high only
         run(sac_gpu, "--encode", flag, str(wav), str(tmp_path / "gpuopt.sac"), env=dict(os.environ, SAC_GPU_OPTIMIZE="1"))
         assert (tmp_path / "gpuopt.sac").read_bytes() == want
+    # the batched binding: Codec::EncodeFile over batches of 2 frames (3 calls for the 2.5 frames), the reference's
+    # Encode() of a batch on 3 host threads while the GPU works on the next batch, records written in frame order: the same file
+    benv = dict(os.environ, SAC_GPU_BATCH="2", SAC_GPU_CODER_THREADS="3")
+    if prof == 2:
+        benv["SAC_GPU_OPTIMIZE"] = "1"
+    out = subprocess.run([sac_gpu, "--encode", flag, str(wav), str(tmp_path / "gpub.sac")], check=True, stdout=subprocess.DEVNULL,
+                         stderr=subprocess.PIPE, text=True, timeout=300, env=benv)
+    assert (tmp_path / "gpub.sac").read_bytes() == want
+    assert 'sac_gpu_timing {' in out.stderr and '"batches": 2' in out.stderr
     run(sac, "--decode", str(tmp_path / "ref.sac"), str(tmp_path / "ref.wav"))
     run(sac_gpu, "--decode", str(tmp_path / "ref.sac"), str(tmp_path / "gpu.wav"))
     assert (tmp_path / "gpu.wav").read_bytes() == (tmp_path / "ref.wav").read_bytes()
