@@ -29,7 +29,7 @@ typedef struct sacopt_ctx sacopt_ctx;
 /* StereoHigh with a 32-tap OLS stage, LPC3(alpha, S = 24, D = 8, k = 8, regp = 500): BASELINE configs[4] ("32-tap OLS + long
  * LMS cascade"). Same 8 coefficients and tables as HIGH. The reference's LPC3 takes S and D as constructor arguments
  * (src/pred/lpc.h:181-185) but no profile it ships uses 24 + 8 (src/profile.cpp:116), so the stage is pinned against the
- * reference class and the cascade against the oracle only. Encoder side only (predict / get_costs / optimize / encode). */
+ * reference class and the cascade -- encoder and decoder side -- against the oracle only ("parity unpinned"). */
 #define SACOPT_PROFILE_HIGH32 3
 #define SACOPT_MAX_COEFS 8
 

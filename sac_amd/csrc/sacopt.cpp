@@ -1676,7 +1676,6 @@ extern "C" int sacopt_unpredict_stereo_frames(sacopt_ctx *c, int profile, int nf
   if (begin_call(c)) return 1;
   ProfDesc pd;
   if (!get_prof(profile, &pd)) { c->err = "unknown profile"; return 1; }
-  if (pd.ols_n != 24) { c->err = "the decoder-side cascade is built for the reference's profiles only (24-tap OLS stage)"; return 1; }
   if (nframes < 0 || (nframes && !frames)) { c->err = "bad arguments"; return 1; }
   if (!nframes) return 0;
   double base[3 * SACOPT_MAX_COEFS];

@@ -75,12 +75,17 @@ __device__ __forceinline__ int unmap_wave(const uint32_t *mp, int pred, int merr
 
 // Out of line: the factorisation holds a matrix row and a solution row per lane (96 VGPRs). Inlined, the allocator
 // spills the per-sample state of every wave around it; as a call, only waves 0/1 pay, every k-th sample.
-template <bool FAST>
-__device__ __noinline__ void chol_wave_call(const double *snap, double *solo, int lane) { chol_wave<FAST>(snap, solo, lane); }
+template <bool FAST, int N>
+__device__ __noinline__ void chol_wave_call(const double *snap, double *solo, int lane) { chol_wave<FAST, N>(snap, solo, lane); }
 
-template <int TYPE>  // 0 fast, 1 normal, 2 high
+template <int TYPE>  // 0 fast, 1 normal, 2 high, 3 high with the 32-tap OLS stage LPC3(alpha, 24, 8, 8, 500) (SACOPT_PROFILE_HIGH32)
 __global__ __launch_bounds__(UN_NT) void k_unpredict(const UnJob *__restrict__ jobs, const uint16_t *__restrict__ gtab, int bits) {
-  constexpr bool BIG = TYPE == 2, LMS = TYPE >= 1;
+  constexpr bool BIG = TYPE >= 2, LMS = TYPE >= 1;
+  // the OLS stage: OL_N taps of which OL_S are the channel's own history (lpc.h:181-185 takes both)
+  constexpr int OL_N = TYPE == 3 ? 32 : 24, OL_S = TYPE == 3 ? 24 : 16, OL_TRI = LPC_TRI_(OL_N), OL_SNAP = LPC_SNAP_(OL_N);
+  constexpr int OL_ROW = OL_N + 1;                            // row stride of the product table (odd: operand reads on different banks)
+  constexpr int NCE = (2 * OL_SNAP + UN_NT - 1) / UN_NT;       // AutoCov elements per thread (1; 2 for the 32-tap stage: 1120 elements)
+  constexpr bool MAPG = TYPE == 3;  // the Unmap tables stay in HBM: with the larger OLS tables the workgroup's LDS has no room for 33 KB more
   constexpr int NS = BIG ? 4 : 3;  // LMS stages (TYPE >= 1): [ (1280,640) ] (256,128) (32,16) (8,4)
   constexpr int KS = TYPE == 0 ? 32 : 8;
   constexpr int SEG = L1_SEG, SEGP = L1_SEGP, NSEG = 15, SB = 1280, MB = 2047;
@@ -93,10 +98,10 @@ __global__ __launch_bounds__(UN_NT) void k_unpredict(const UnJob *__restrict__ j
   __shared__ double sA[16], sX1;
   __shared__ uint16_t tab[LMS ? RSQ_LDS_MAX : 1];
   __shared__ double vh[2][64];  // decoded samples as doubles, [t & 63]
-  __shared__ double snapL[2][LPC_SNAP], solL[2][LPC_TRI];
+  __shared__ double snapL[2][OL_SNAP], solL[2][OL_TRI];
   __shared__ double pst[8];      // p[0..NS] of the channel being decoded (profile.cpp:128-132)
   __shared__ double errL[2][4];  // val[c][k+1] - p[k+1]: LMSADA2::Update's err (nlms.h:116) per stage
-  __shared__ uint32_t mapL[2][2 * UN_MAPW];
+  __shared__ uint32_t mapL[2][MAPG ? 1 : 2 * UN_MAPW];
   __shared__ int32_t ebuf[2][UN_IO], vbuf[2][UN_IO];
   // state only one wave touches lives in LDS, [slot][lane], not in registers (a 1024-thread workgroup has 128 per lane):
   // BlendErr of wave 6 (slots c: ssum, 2+c: serr, 4+c: w, 6+c: pm), RLS of wave 7 (0: P[i][j], 1..4: w, 5+4c+k: hist,
@@ -108,8 +113,8 @@ __global__ __launch_bounds__(UN_NT) void k_unpredict(const UnJob *__restrict__ j
   // LPC3::Predict on the matrix pipe: products sol[o][i]*hist[i] as a 24 x 24 table (row stride 25: the 16 chain lanes of
   // an operand read on different banks; entries i > o stay +0, which leaves a sum that started at +0 unchanged),
   // the products w[o]*ssum[o] of BlendErr::Predict, and (order << 8 | i) of every packed solution entry
-  __shared__ double prodL[LMS ? LPC_N * 25 : 1], prodP[LPC_N];
-  __shared__ uint16_t triL[LMS ? LPC_TRI : 1];
+  __shared__ double prodL[LMS ? OL_N * OL_ROW : 1], prodP[OL_N];
+  __shared__ uint16_t triL[LMS ? OL_TRI : 1];
 
   const UnJob &job = jobs[blockIdx.x];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), n = job.n;  // wave: an SGPR, roles branch on it
@@ -123,9 +128,9 @@ __global__ __launch_bounds__(UN_NT) void k_unpredict(const UnJob *__restrict__ j
   if (tid < 32) (&ringT[0][0])[tid] = 0.;
   if (tid < 16) prodsT[tid] = 0.;
   if (tid < 128) (&vh[0][0])[tid] = 0.;
-  for (int i = tid; i < 2 * LPC_TRI; i += UN_NT) (&solL[0][0])[i] = 0.;
-  if (mapped0) for (int i = tid; i < 2 * UN_MAPW; i += UN_NT) mapL[0][i] = job.map[0][i];
-  if (mapped1) for (int i = tid; i < 2 * UN_MAPW; i += UN_NT) mapL[1][i] = job.map[1][i];
+  for (int i = tid; i < 2 * OL_TRI; i += UN_NT) (&solL[0][0])[i] = 0.;
+  if (!MAPG && mapped0) for (int i = tid; i < 2 * UN_MAPW; i += UN_NT) mapL[0][i] = job.map[0][i];
+  if (!MAPG && mapped1) for (int i = tid; i < 2 * UN_MAPW; i += UN_NT) mapL[1][i] = job.map[1][i];
 
   // ---- per-thread state
   // (1280,640): wave s owns segment s (taps 128 s + 64 r + lane), for both channels
@@ -143,30 +148,32 @@ __global__ __launch_bounds__(UN_NT) void k_unpredict(const UnJob *__restrict__ j
   if (LMS) for (int i = tid; i < 4 * 384; i += UN_NT) (&lmM[0][0])[i] = 0.;
   if (tid < 4 * 64) (&lmS[0][0])[tid] = 0.;  // (32,16) or (8,4) tap of wave 15
   if (LMS) {
-    for (int i = tid; i < LPC_N * 25; i += UN_NT) prodL[i] = 0.;
-    for (int e = tid; e < LPC_TRI; e += UN_NT) {
+    for (int i = tid; i < OL_N * OL_ROW; i += UN_NT) prodL[i] = 0.;
+    for (int e = tid; e < OL_TRI; e += UN_NT) {
       int o = 0;
       while ((o + 1) * (o + 2) / 2 <= e) o++;
       triL[e] = (uint16_t)((o << 8) | (e - o * (o + 1) / 2));
     }
   }
-  // AutoCov element (cov.h:13-51): threads 0..647, channel tid / 324
-  int cpack;  // ci | cj << 8 | channel << 16 | isc << 17 | valid << 18: one register across the loop
-  double cv;
-  {
-    const int cch = tid / LPC_SNAP, ce = tid - cch * LPC_SNAP;
-    const bool vC = tid < 2 * LPC_SNAP, isc = ce < LPC_TRI;
+  // AutoCov elements (cov.h:13-51): element e = tid + UN_NT * u of 2 * OL_SNAP (648: one per thread; 1120: up to two), channel e / OL_SNAP
+  int cpack[NCE];  // ci | cj << 8 | channel << 16 | isc << 17 | valid << 18: one register per element across the loop
+  double cv[NCE];
+#pragma unroll
+  for (int u = 0; u < NCE; u++) {
+    const int el = tid + UN_NT * u;
+    const int cch = el / OL_SNAP, ce = el - cch * OL_SNAP;
+    const bool vC = el < 2 * OL_SNAP, isc = ce < OL_TRI;
     int cj = 0, ci = 0;
     if (isc) { while ((cj + 1) * (cj + 2) / 2 <= ce) cj++; ci = ce - cj * (cj + 1) / 2; }
-    else ci = ce - LPC_TRI;
-    cv = (vC && isc && ci == cj) ? 1.0 : 0.0;  // cov.h:17
-    cpack = ci | (cj << 8) | (cch << 16) | ((int)isc << 17) | ((int)vC << 18);
+    else ci = ce - OL_TRI;
+    cv[u] = (vC && isc && ci == cj) ? 1.0 : 0.0;  // cov.h:17
+    cpack[u] = ci | (cj << 8) | ((cch & 1) << 16) | ((int)isc << 17) | ((int)vC << 18);
   }
   const double alpha = job.coef[0];
-  // hist[i] of LPC channel ch at time t (cov.h:44-47 as indices): i < 16 own v(t-1-i), else other v(t - lagb - (i-16))
+  // hist[i] of LPC channel ch at time t (cov.h:44-47 as indices): i < OL_S own v(t-1-i), else other v(t - lagb - (i-OL_S))
   auto lpc_h = [&](int ch, int i, int t) -> double {
-    const int idx = (i < LPC_S) ? (t - 1 - i) : (t - (ch == 0 ? 1 : 0) - (i - LPC_S));
-    return vh[(i < LPC_S) ? ch : 1 - ch][idx & 63];
+    const int idx = (i < OL_S) ? (t - 1 - i) : (t - (ch == 0 ? 1 : 0) - (i - OL_S));
+    return vh[(i < OL_S) ? ch : 1 - ch][idx & 63];
   };
   // BlendErr (blend.h:7-53) of both channels: wave 6, lane o = order o, lane 24 = the blended prediction's error
   for (int i = tid; i < 8 * 64; i += UN_NT) (&blS[0][0])[i] = 0.;
@@ -298,44 +305,46 @@ __global__ __launch_bounds__(UN_NT) void k_unpredict(const UnJob *__restrict__ j
           // table; the 24 sums are MFMA adder chains (B == 1: ((C + a0) + a1) + a2) + a3 per step, IEEE rounding after
           // each add, terms in the reference's order i = 0, 1, ...), 16 orders per instruction, 6 steps.
 #pragma unroll
-          for (int q = 0; q < 5; q++) {
+          for (int q = 0; q < (OL_TRI + 63) / 64; q++) {
             const int e = lane + 64 * q;
-            if (e < LPC_TRI) {
+            if (e < OL_TRI) {
               const int oi = triL[e], i = oi & 255;
-              prodL[(oi >> 8) * 25 + i] = solL[c][e] * lpc_h(c, i, t);
+              prodL[(oi >> 8) * OL_ROW + i] = solL[c][e] * lpc_h(c, i, t);
             }
           }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
-          const int r0 = (lane & 15) * 25 + mk, r1 = ((lane & 15) < 8 ? 16 + (lane & 15) : 23) * 25 + mk;  // orders 0..15 | 16..23 (rest: copies)
-          double a0[6], a1[6], acc0 = 0., acc1 = 0.;
+          constexpr int NQ = OL_N / 4;  // MFMA steps of an order's sum
+          const int r0 = (lane & 15) * OL_ROW + mk;                                                       // orders 0..15
+          const int r1 = (16 + (lane & 15) < OL_N ? 16 + (lane & 15) : OL_N - 1) * OL_ROW + mk;         // orders 16..OL_N-1 (rest: copies)
+          double a0[NQ], a1[NQ], acc0 = 0., acc1 = 0.;
 #pragma unroll
-          for (int u = 0; u < 6; u++) { a0[u] = prodL[r0 + 4 * u]; a1[u] = prodL[r1 + 4 * u]; }
+          for (int u = 0; u < NQ; u++) { a0[u] = prodL[r0 + 4 * u]; a1[u] = prodL[r1 + 4 * u]; }
 #pragma unroll
-          for (int u = 0; u < 6; u++) {
+          for (int u = 0; u < NQ; u++) {
             acc0 = __builtin_amdgcn_mfma_f64_4x4x4f64(a0[u], 1.0, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f64_4x4x4f64(a1[u], 1.0, acc1, 0, 0, 0);
           }
           const int jD = 4 * ((lane >> 2) & 3) + (lane >> 4);  // chain of this D-layout lane
           if ((lane & 3) == 0) {
             blS[c][jD] = acc0;
-            if (jD < 8) blS[c][16 + jD] = acc1;
+            if (16 + jD < OL_N) blS[c][16 + jD] = acc1;
           }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
-          if (lane < LPC_N) prodP[lane] = blS[4 + c][lane] * blS[c][lane];
+          if (lane < OL_N) prodP[lane] = blS[4 + c][lane] * blS[c][lane];
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
-          double ap[6], pm = 0.;
+          double ap[NQ], pm = 0.;
 #pragma unroll
-          for (int u = 0; u < 6; u++) ap[u] = prodP[4 * u + mk];
+          for (int u = 0; u < NQ; u++) ap[u] = prodP[4 * u + mk];
 #pragma unroll
-          for (int u = 0; u < 6; u++) pm = __builtin_amdgcn_mfma_f64_4x4x4f64(ap[u], 1.0, pm, 0, 0, 0);
-          if (lane == 0) { pst[0] = pm; blS[6 + c][LPC_N] = pm; }  // slot LPC_N: the error of the blend itself (blend.h:38)
+          for (int u = 0; u < NQ; u++) pm = __builtin_amdgcn_mfma_f64_4x4x4f64(ap[u], 1.0, pm, 0, 0, 0);
+          if (lane == 0) { pst[0] = pm; blS[6 + c][OL_N] = pm; }  // slot OL_N: the error of the blend itself (blend.h:38)
         } else {  // LPC2::Predict (lpc.h:261-267)
           double p = 0.;
 #pragma unroll
-          for (int i = 0; i < LPC_N; i++) p += solL[c][i] * lpc_h(c, i, t);
+          for (int i = 0; i < OL_N; i++) p += solL[c][i] * lpc_h(c, i, t);
           if (lane == 0) pst[0] = p;
         }
       }
@@ -361,7 +370,7 @@ __global__ __launch_bounds__(UN_NT) void k_unpredict(const UnJob *__restrict__ j
           int32_t q = cvt_i32_x86(round(pst[0] + pc));
           if (BIG) q = q < mnv[c] ? mnv[c] : (q > mxv[c] ? mxv[c] : q);  // profile.cpp:163,170
           int32_t e = e_in;
-          if (c == 0 ? mapped0 : mapped1) e = unmap_wave(mapL[c], q, e, lane);
+          if (c == 0 ? mapped0 : mapped1) e = unmap_wave(MAPG ? job.map[c] : mapL[c], q, e, lane);
           v = (int32_t)((uint32_t)e + (uint32_t)q);  // wraps like the reference build
           val[0] = (double)v;
 #pragma unroll
@@ -422,13 +431,13 @@ __global__ __launch_bounds__(UN_NT) void k_unpredict(const UnJob *__restrict__ j
         const int c = wave == 6 ? 0 : 1;
         {
           const double val = vh[c][t & 63];
-          const double e = val - (lane == LPC_N ? blS[6 + c][lane] : blS[c][lane]);
+          const double e = val - (lane == OL_N ? blS[6 + c][lane] : blS[c][lane]);
           const double se = 0.98 * blS[2 + c][lane] + (1. - 0.98) * (e * e);
           blS[2 + c][lane] = se;
           const double tt = 10000. / (se + 0.0001);
           double wv = tt * tt, wsum = 0;
 #pragma unroll
-          for (int i = 0; i < LPC_N; i++) wsum += bcast(wv, i);
+          for (int i = 0; i < OL_N; i++) wsum += bcast(wv, i);
           if (wsum > 0) wv /= wsum;
           blS[4 + c][lane] = wv;
         }
@@ -468,20 +477,25 @@ __global__ __launch_bounds__(UN_NT) void k_unpredict(const UnJob *__restrict__ j
         for (int k = 0; k < NS; k++) rlS[1 + k][lane] = rlS[1 + k][lane] + dv * kk[k];
       }
     }
-    const int ci = cpack & 255, cj = (cpack >> 8) & 255, cch = (cpack >> 16) & 1;
-    const bool isc = (cpack >> 17) & 1, vC = (cpack >> 18) & 1;
-    if (vC) {  // AutoCov::UpdateCov / UpdateB (cov.h:19-43)
-      const double hi = lpc_h(cch, ci, t);
-      const double hj = isc ? lpc_h(cch, cj, t) : vh[cch][t & 63];
-      if (isc) cv = alpha * cv + (hi * hj);
-      else cv = alpha * cv + (hj * hi);
+#pragma unroll
+    for (int u = 0; u < NCE; u++) {
+      const int ci = cpack[u] & 255, cj = (cpack[u] >> 8) & 255, cch = (cpack[u] >> 16) & 1;
+      const bool isc = (cpack[u] >> 17) & 1, vC = (cpack[u] >> 18) & 1;
+      if (vC) {  // AutoCov::UpdateCov / UpdateB (cov.h:19-43)
+        const double hi = lpc_h(cch, ci, t);
+        const double hj = isc ? lpc_h(cch, cj, t) : vh[cch][t & 63];
+        if (isc) cv[u] = alpha * cv[u] + (hi * hj);
+        else cv[u] = alpha * cv[u] + (hj * hi);
+      }
     }
     UN_BUSY(pwD)
     UN_TICK(pfD)
     if (((t + 1) % KS) == 0) {  // lpc.h:213-219 / :277-283
-      if (vC) snapL[cch][tid - cch * LPC_SNAP] = cv;
+#pragma unroll
+      for (int u = 0; u < NCE; u++)
+        if ((cpack[u] >> 18) & 1) (&snapL[0][0])[tid + UN_NT * u] = cv[u];  // (element e of channel e / OL_SNAP: the two snapshots are contiguous)
       __syncthreads();
-      if (wave < 2) chol_wave_call<TYPE == 0>(snapL[wave], solL[wave], lane);  // "matrix indefinit": the previous solution stays
+      if (wave < 2) chol_wave_call<TYPE == 0, OL_N>(snapL[wave], solL[wave], lane);  // "matrix indefinit": the previous solution stays
       __syncthreads();
       UN_TICK(pfK)
     }
@@ -508,6 +522,7 @@ extern "C" int sacopt_launch_unpredict(int type, const UnJob *jobs, int njobs, c
   if (type == 0) hipLaunchKernelGGL(k_unpredict<0>, dim3(njobs), dim3(UN_NT), 0, st, jobs, tab, bits);
   else if (type == 1) hipLaunchKernelGGL(k_unpredict<1>, dim3(njobs), dim3(UN_NT), 0, st, jobs, tab, bits);
   else if (type == 2) hipLaunchKernelGGL(k_unpredict<2>, dim3(njobs), dim3(UN_NT), 0, st, jobs, tab, bits);
+  else if (type == 3) hipLaunchKernelGGL(k_unpredict<3>, dim3(njobs), dim3(UN_NT), 0, st, jobs, tab, bits);
   else return 1;
   return hipGetLastError() != hipSuccess;
 }

@@ -110,8 +110,19 @@ def test_ols32_cascade_vs_oracle(ctx, golden, c5, oracle):
     ref = oracle.predict(3, L, R, maps=True)
     for k in ("e0", "e1", "u0", "u1", "m0", "m1", "maxbpn"):
         assert np.array_equal(o[k], ref[k]), k
-    with pytest.raises(sacopt.SacoptError, match="24-tap"):
-        ctx.unpredict(3, [dict(e0=o["e0"], e1=o["e1"])])
+    # ... and back: the decoder-side cascade with the 32-tap stage (k_unpredict<3>), against the oracle's decoder and the input;
+    # channel 1 mapped (Remap::Unmap from tables in HBM), custom coefficients
+    dec = ctx.unpredict(3, [dict(e0=o["e0"], e1=o["e1"])])[0]
+    od = oracle.unpredict(3, o["e0"], o["e1"])
+    assert np.array_equal(dec[0], od[0]) and np.array_equal(dec[1], od[1]) and np.array_equal(dec[0], L) and np.array_equal(dec[1], R)
+    cf = sacopt.base_profile(3)[:, 2].copy(); cf[0] = 0.9985; cf[2] = 2e-5; cf[7] = 0.9995
+    Ls, Rs = (L[:9000] // 3) * 3, R[:9000]
+    enc = ctx.predict(3, [(Ls, Rs)], coefs=cf[None, :], maps=True)[0]
+    m0 = np.where(enc["m0"] & 1, (enc["m0"].astype(np.int64) + 1) >> 1, -(enc["m0"].astype(np.int64) >> 1)).astype(np.int32)   # U2S (utils.h:62-66)
+    u0 = oracle.remap_tables(Ls)
+    dec = ctx.unpredict(3, [dict(e0=m0, e1=enc["e1"], used0=u0)], coefs=cf[None, :])[0]
+    od = oracle.unpredict(3, m0, enc["e1"], coefs=cf, used0=u0)
+    assert np.array_equal(dec[0], od[0]) and np.array_equal(dec[1], od[1]) and np.array_equal(dec[0], Ls) and np.array_equal(dec[1], Rs)
 
 
 def test_config5_ols32_optimizer_vs_oracle(ctx, c5):
@@ -122,7 +133,7 @@ def test_config5_ols32_optimizer_vs_oracle(ctx, c5):
 
 
 # ---------------------------------------------------------------- the optimiser's parameters in the stream
-@pytest.mark.parametrize("prof", [0, 1, 2])
+@pytest.mark.parametrize("prof", [0, 1, 2, 3])
 def test_parameter_stream_round_trip(prof):
     # opt-in extension (sac_amd/host/sacfile.h): header flag + per-frame {coefs, minval/maxval}. Encode: Optimize, then
     # PredictStereoFrame with the WINNERS (two GPU passes), reference bit-plane coder, container writer. Decode: container
@@ -130,6 +141,7 @@ def test_parameter_stream_round_trip(prof):
     if not oracle_lib.have_ref():
         pytest.skip("oracle/_ref not built")
     ref = oracle_lib.Ref()
+    cprof = min(prof, 2)   # the reference's coder does not depend on the predictor profile; it knows no profile 3 (HIGH32: parity unpinned)
     rate, n = 2000, 19000
     L, R = stereo_clip(601, n, rate=rate)
     fs = 4 * rate
@@ -140,7 +152,7 @@ def test_parameter_stream_round_trip(prof):
         nolimit = (-2 ** 31, 2 ** 31 - 1, -2 ** 31, 2 ** 31 - 1)   # StereoHigh::Unpredict's clamp (profile.cpp:163,170) made a no-op:
         blob = sacfile.write_header(2, rate, 16, n, prof | sacfile.PROFILE_PARAMS, sacfile.canonical_wav_metadata(2, rate, 16, n))
         for (l, r), o, b in zip(frames, outs, best):               # the encoder does not clamp, so the decoder must not either
-            ch = oracle_lib.ref_encode_channels(ref, prof, l, r, o)
+            ch = oracle_lib.ref_encode_channels(ref, cprof, l, r, o)
             blob += sacfile.write_frame(len(l), ch[0], ch[1], params=(b, nolimit))
         # ---- decode from the bytes alone
         hdr, pos = sacfile.read_header(blob)
@@ -151,7 +163,7 @@ def test_parameter_stream_round_trip(prof):
             rec, used = sacfile.read_frame(blob, pos, with_params=True)
             pos += used
             left -= rec["numsamples"]
-            e0, e1, u0, u1 = oracle_lib.ref_decode_channels(ref, prof, rec["numsamples"], rec["ch"][0], rec["ch"][1])
+            e0, e1, u0, u1 = oracle_lib.ref_decode_channels(ref, cprof, rec["numsamples"], rec["ch"][0], rec["ch"][1])
             dec_in.append(dict(e0=e0, e1=e1, used0=u0, used1=u1, minmax=rec["minmax"]))
             coefs.append(rec["coefs"])
         assert pos == len(blob)

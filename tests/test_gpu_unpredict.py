@@ -143,10 +143,11 @@ def test_full_size_round_trip_config5(ctx):
     base = sacopt.base_profile(2)[:, 2]
     coefs = np.tile(base, (4, 1))
     coefs[1, 0] = 0.9985; coefs[2, 1] = 2e-5; coefs[3, 7] = 0.9995
-    enc = ctx.predict(2, frames, coefs=coefs)
-    dec = ctx.unpredict(2, [dict(e0=d["e0"], e1=d["e1"]) for d in enc], coefs=coefs)
-    for (L, R), v in zip(frames, dec):
-        assert np.array_equal(v[0], L) and np.array_equal(v[1], R)
+    for prof in (2, 3):   # 3 = SACOPT_PROFILE_HIGH32, "32-tap OLS + long LMS cascade" (parity unpinned: no reference profile has the shape)
+        enc = ctx.predict(prof, frames, coefs=coefs)
+        dec = ctx.unpredict(prof, [dict(e0=d["e0"], e1=d["e1"]) for d in enc], coefs=coefs)
+        for (L, R), v in zip(frames, dec):
+            assert np.array_equal(v[0], L) and np.array_equal(v[1], R), prof
 
 
 def test_unpredict_error_paths(ctx):
