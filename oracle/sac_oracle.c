@@ -665,12 +665,12 @@ static void stereo_unstep(stereo_t *s, int32_t e0, int32_t e1, const remap_t *ma
     int32_t p0 = (int32_t)round(cascade_predict(s, 0, 1));
     if (s->type >= 2) p0 = clamp_i32(p0, minval[0], maxval[0]);
     if (map0) e0 = remap_unmap(map0, p0, e0);
-    *v0 = e0 + p0;
+    *v0 = (int32_t)((uint32_t)e0 + (uint32_t)p0); /* garbage streams: the reference's int add overflows (UB); its build wraps */
     cascade_calc_error(s, 0, *v0);
     int32_t p1 = (int32_t)round(cascade_predict(s, 1, 0));
     if (s->type >= 2) p1 = clamp_i32(p1, minval[1], maxval[1]);
     if (map1) e1 = remap_unmap(map1, p1, e1);
-    *v1 = e1 + p1;
+    *v1 = (int32_t)((uint32_t)e1 + (uint32_t)p1);
     cascade_calc_error(s, 1, *v1);
     cascade_update(s);
   }

@@ -28,6 +28,7 @@ int sachost_write_header(uint32_t numch, uint32_t rate, uint32_t bits, uint32_t 
 // fields: numch, rate, bits, numsamples, profile, metadata length; the metadata starts at byte 24. Returns bytes consumed (0 = error).
 int sachost_read_header(const uint8_t *p, int len, uint32_t *fields) {
   SacHeader h;
+  if (len < 0 || !p) return 0;
   const size_t used = ReadHeader(p, (size_t)len, h);
   if (!used) return 0;
   fields[0] = h.numchannels; fields[1] = h.samplerate; fields[2] = h.bitspersample; fields[3] = h.numsamples;
@@ -55,6 +56,7 @@ int sachost_write_frame(uint32_t numsamples, const uint8_t *p0, int len0, const 
 int sachost_read_frame(const uint8_t *p, int len, int with_params, uint32_t *numsamples, int32_t *chan, int32_t *ncoef,
                        double *coefs, int32_t *minmax) {
   FrameRecord f;
+  if (len < 0 || !p) return 0;
   const size_t used = ReadEncoded(p, (size_t)len, f, with_params != 0);
   if (!used) return 0;
   *numsamples = f.numsamples;
