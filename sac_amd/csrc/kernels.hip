@@ -561,6 +561,13 @@ __device__ __forceinline__ double spec_exact_sum(uint32_t prods_addr, int (*sJ)[
 // ------------------------------------------------------------------------------------------
 #define L1_SEG 128   // products per segment (32 MFMA steps)
 #define L1_SEGP 130  // segment stride in LDS: the 16 chain lanes of a ds_read_b64 half on 16 different 4-bank groups
+// The samples a launch covers: [job.t0, job.t0 + job.n) as the job says (clen == 0), or -- chunk launches of one shared job table,
+// whose jobs describe the WHOLE window [0, job.n) -- the chunk [ct0, ct0 + clen) clipped to the window; a chain whose window
+// ends before the chunk has nothing to do (its workgroup leaves at once: nothing loaded, nothing stored).
+#define LMS_SPAN(job, ct0, clen)                                                                        \
+  const int t0 = (clen) > 0 ? (ct0) : (job).t0;                                                         \
+  const int tend = (clen) > 0 ? ((job).n < (ct0) + (clen) ? (job).n : (ct0) + (clen)) : (job).t0 + (job).n; \
+  if ((clen) > 0 && (ct0) > 0 && tend <= t0) return;
 #ifndef S2_CHP
 #define S2_CHP LMS_CHUNK  // two-channel (1280,640) kernel: samples staged per refill
 #endif
@@ -582,7 +589,7 @@ static_assert(H_SPLIT == 192 || H_SPLIT == 224, "chains exist for 192 + 192 and 
 #endif
 template <int S, int D, int NT, int R, int RL, bool SPEC, int CHP = LMS_CHUNK>
 __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, const uint16_t *__restrict__ gtab,
-                                            int bits) {
+                                            int bits, int ct0, int clen) {
   constexpr int T = S + D, T4 = T / 4, M = RL - 1, CH = CHP;  // CH: samples staged per refill (divides LMS_CHUNK, the unit of the host's chunk edges)
   static_assert(LMS_CHUNK % CHP == 0, "refill size must divide LMS_CHUNK");
   // SPEC: 15 segments of 128 products, padded to a stride of 130 doubles so that the 16 segment
@@ -614,7 +621,8 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
   __shared__ double hX1[2], hOut[2][64], hGb[2], hIu[2], hU[2], hP2[2];
 
   const LmsJob job = jobs[blockIdx.x];
-  const int tid = threadIdx.x, t0 = job.t0, tend = job.t0 + job.n;
+  LMS_SPAN(job, ct0, clen)
+  const int tid = threadIdx.x;
 #ifdef SACOPT_ABLATE
   const int dbg = bits >> 8;  // A/B timing switches of tools/ builds (tools/ablate.py): 2 = skip the update, 16 = single P2 pass
 #else
@@ -903,7 +911,7 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
 #define S2_NT 512
 #define S2_CH 128
 #define S2_HL (1280 + S2_CH)
-__global__ __launch_bounds__(S2_NT, 4) void k_lms2(const LmsJob *__restrict__ jobs, const uint16_t *__restrict__ gtab, int bits) {
+__global__ __launch_bounds__(S2_NT, 4) void k_lms2(const LmsJob *__restrict__ jobs, const uint16_t *__restrict__ gtab, int bits, int ct0, int clen) {
   constexpr int S = 1280, T = 1920, NT = S2_NT, CH = S2_CH, HL = S2_HL, R = 8;
   constexpr int SEG = L1_SEG, SEGP = L1_SEGP, NSEG = 15, TP = 16 * SEGP;
   __shared__ __attribute__((aligned(256))) uint16_t tab[RSQ_LDS_MAX];
@@ -915,7 +923,8 @@ __global__ __launch_bounds__(S2_NT, 4) void k_lms2(const LmsJob *__restrict__ jo
   __shared__ double sA[2][16];
 
   const LmsJob job = jobs[blockIdx.x];
-  const int tid = threadIdx.x, t0 = job.t0, tend = job.t0 + job.n;
+  LMS_SPAN(job, ct0, clen)
+  const int tid = threadIdx.x;
 #ifdef SACOPT_ABLATE
   const int dbg = bits >> 8;
 #else
@@ -1099,7 +1108,7 @@ __global__ __launch_bounds__(S2_NT, 4) void k_lms2(const LmsJob *__restrict__ jo
 #define L1_RLO 2048
 #define L1_RLX 1024
 
-__global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs, const uint16_t *__restrict__ gtab, int bits) {
+__global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs, const uint16_t *__restrict__ gtab, int bits, int ct0, int clen) {
   constexpr int S = 1280, T = 1920, NT = L1_NT, R = L1_R, CH = L1_CH, MO = L1_RLO - 1, MX = L1_RLX - 1;
   constexpr int SEG = L1_SEG, SEGP = L1_SEGP, NSEG = T / SEG;  // 15 segments of 128 products
   __shared__ double prods[16 * SEGP];  // (one buffer also with early prediction: the verifier works from registers)
@@ -1129,7 +1138,8 @@ __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs
   double *pout = c ? job.p[1] : job.p[0];
   double *xnout = c ? job.xn[1] : job.xn[0];
   const int lagx = c ? 0 : 1;  // ch0: Predict(x1(t-1)); ch1: Predict(x0(t))  (profile.cpp:128-132)
-  const int tid = threadIdx.x, t0 = job.t0, tend = job.t0 + job.n;
+  LMS_SPAN(job, ct0, clen)
+  const int tid = threadIdx.x;
 #ifdef SACOPT_ABLATE
   const int dbg = bits >> 8;
 #else
@@ -1725,12 +1735,17 @@ __device__ __forceinline__ double pick(const double (&a)[NS], int k) {  // a[k] 
 }
 
 template <int NS>
-__global__ __launch_bounds__(64) void k_mix(const MixJob *__restrict__ jobs, int njobs) {
+__global__ __launch_bounds__(64) void k_mix(const MixJob *__restrict__ jobs, int njobs, int ct0, int clen) {
   const int lane = threadIdx.x, i = (lane >> 2) & 3, j = lane & 3, base16 = lane & ~15;
   const int unit = blockIdx.x * 4 + (lane >> 4);
-  const bool live = unit < 2 * njobs;
+  bool live = unit < 2 * njobs;
   const MixJob &job = jobs[live ? (unit >> 1) : 0];
-  const int ch = unit & 1, t0 = job.t0, n = live ? job.n : 0;
+  // (clen > 0: chunk [ct0, ct0 + clen) of a job that describes the whole window, see LMS_SPAN; a unit whose window ends before the
+  // chunk is not live: it stores nothing)
+  const int ch = unit & 1, t0 = clen > 0 ? ct0 : job.t0;
+  const int nspan = clen > 0 ? (job.n - ct0 < clen ? job.n - ct0 : clen) : job.n;
+  if (clen > 0 && ct0 > 0 && nspan <= 0) live = false;
+  const int n = live ? (nspan > 0 ? nspan : 0) : 0;
   const double alpha = job.alpha;
   const int32_t *s = job.s[ch];
   const double *p0 = job.p0[ch], *x1 = job.x1[ch];
@@ -2192,29 +2207,30 @@ extern "C" int sacopt_lms_variant(int S, int D, int njobs, int bits, int limit) 
   if (S != 1280 || D != 640) return 0;
   return (!(ABL_SW(bits) & (8 | 256)) && (njobs <= limit || (ABL_SW(bits) & 512))) ? 1 : 0;
 }
+// ct0 / clen: see LMS_SPAN (0, 0: every job carries its own span)
 extern "C" int sacopt_launch_lms(int S, int D, const LmsJob *jobs, int njobs, const uint16_t *tab, int bits,
-                                 hipStream_t st, int limit) {
+                                 hipStream_t st, int limit, int ct0, int clen) {
   if (njobs <= 0) return 0;
   if (S == 1280 && D == 640) {
-    if (sacopt_lms_variant(S, D, njobs, bits, limit)) hipLaunchKernelGGL(k_lms1c, dim3(2 * njobs), dim3(L1_NT), 0, st, jobs, tab, bits);
-    else if (ABL_SW(bits) & 8) hipLaunchKernelGGL((k_lms<1280, 640, 1024, 4, 2048, false>), dim3(njobs), dim3(1024), 0, st, jobs, tab, bits);
+    if (sacopt_lms_variant(S, D, njobs, bits, limit)) hipLaunchKernelGGL(k_lms1c, dim3(2 * njobs), dim3(L1_NT), 0, st, jobs, tab, bits, ct0, clen);
+    else if (ABL_SW(bits) & 8) hipLaunchKernelGGL((k_lms<1280, 640, 1024, 4, 2048, false>), dim3(njobs), dim3(1024), 0, st, jobs, tab, bits, ct0, clen);
     // 1024 threads are faster for a chain alone (9.4k against 10.0k cycles per sample) but slower in the optimizer's
     // rounds, where the follower stages want room on the same CUs (optimize 571 against 526 ms): A/B switch only
-    else if (ABL_SW(bits) & 4096) hipLaunchKernelGGL((k_lms<1280, 640, 1024, 4, 2048, true>), dim3(njobs), dim3(1024), 0, st, jobs, tab, bits);
-    else if (ABL_SW(bits) & 16384) hipLaunchKernelGGL((k_lms<1280, 640, 512, 8, 2048, true, S2_CHP>), dim3(njobs), dim3(512), 0, st, jobs, tab, bits);
-    else hipLaunchKernelGGL(k_lms2, dim3(njobs), dim3(S2_NT), 0, st, jobs, tab, bits);
+    else if (ABL_SW(bits) & 4096) hipLaunchKernelGGL((k_lms<1280, 640, 1024, 4, 2048, true>), dim3(njobs), dim3(1024), 0, st, jobs, tab, bits, ct0, clen);
+    else if (ABL_SW(bits) & 16384) hipLaunchKernelGGL((k_lms<1280, 640, 512, 8, 2048, true, S2_CHP>), dim3(njobs), dim3(512), 0, st, jobs, tab, bits, ct0, clen);
+    else hipLaunchKernelGGL(k_lms2, dim3(njobs), dim3(S2_NT), 0, st, jobs, tab, bits, ct0, clen);
   }
   // follower stages: short rings (128 samples per refill) keep their LDS small, so that more of them share a CU and
   // fit beside a lead workgroup (A/B switch 8192: the 512-sample instances)
   else if (ABL_SW(bits) & 8192) {
-    if (S == 256 && D == 128) hipLaunchKernelGGL((k_lms<256, 128, 256, 3, 1024, false>), dim3(njobs), dim3(256), 0, st, jobs, tab, bits);
-    else if (S == 32 && D == 16) hipLaunchKernelGGL((k_lms<32, 16, 64, 2, 1024, false>), dim3(njobs), dim3(64), 0, st, jobs, tab, bits);
-    else if (S == 8 && D == 4) hipLaunchKernelGGL((k_lms<8, 4, 64, 1, 1024, false>), dim3(njobs), dim3(64), 0, st, jobs, tab, bits);
+    if (S == 256 && D == 128) hipLaunchKernelGGL((k_lms<256, 128, 256, 3, 1024, false>), dim3(njobs), dim3(256), 0, st, jobs, tab, bits, ct0, clen);
+    else if (S == 32 && D == 16) hipLaunchKernelGGL((k_lms<32, 16, 64, 2, 1024, false>), dim3(njobs), dim3(64), 0, st, jobs, tab, bits, ct0, clen);
+    else if (S == 8 && D == 4) hipLaunchKernelGGL((k_lms<8, 4, 64, 1, 1024, false>), dim3(njobs), dim3(64), 0, st, jobs, tab, bits, ct0, clen);
     else return 1;
   }
-  else if (S == 256 && D == 128) hipLaunchKernelGGL((k_lms<256, 128, H2_NT, H2_R, 512, false, 128>), dim3(njobs), dim3(H2_NT), 0, st, jobs, tab, bits);
-  else if (S == 32 && D == 16) hipLaunchKernelGGL((k_lms<32, 16, 64, 2, 256, false, 128>), dim3(njobs), dim3(64), 0, st, jobs, tab, bits);
-  else if (S == 8 && D == 4) hipLaunchKernelGGL((k_lms<8, 4, 64, 1, 256, false, 128>), dim3(njobs), dim3(64), 0, st, jobs, tab, bits);
+  else if (S == 256 && D == 128) hipLaunchKernelGGL((k_lms<256, 128, H2_NT, H2_R, 512, false, 128>), dim3(njobs), dim3(H2_NT), 0, st, jobs, tab, bits, ct0, clen);
+  else if (S == 32 && D == 16) hipLaunchKernelGGL((k_lms<32, 16, 64, 2, 256, false, 128>), dim3(njobs), dim3(64), 0, st, jobs, tab, bits, ct0, clen);
+  else if (S == 8 && D == 4) hipLaunchKernelGGL((k_lms<8, 4, 64, 1, 256, false, 128>), dim3(njobs), dim3(64), 0, st, jobs, tab, bits, ct0, clen);
   else return 1;
   return hipGetLastError() != hipSuccess;
 }
@@ -2244,11 +2260,11 @@ extern "C" int sacopt_launch_lpc2(const LpcJob *jobs, int njobs, int max_n, hipS
   hipLaunchKernelGGL(k_pred2, dim3((max_n + 255) / 256, 2 * njobs), dim3(256), 0, st, jobs);
   return hipGetLastError() != hipSuccess;
 }
-extern "C" int sacopt_launch_mix(int ns, const MixJob *jobs, int njobs, hipStream_t st) {
+extern "C" int sacopt_launch_mix(int ns, const MixJob *jobs, int njobs, hipStream_t st, int ct0, int clen) {
   if (njobs <= 0) return 0;
   const int blocks = (2 * njobs + 3) / 4;
-  if (ns == 4) hipLaunchKernelGGL((k_mix<4>), dim3(blocks), dim3(64), 0, st, jobs, njobs);  // 4 units per wave
-  else if (ns == 3) hipLaunchKernelGGL((k_mix<3>), dim3(blocks), dim3(64), 0, st, jobs, njobs);
+  if (ns == 4) hipLaunchKernelGGL((k_mix<4>), dim3(blocks), dim3(64), 0, st, jobs, njobs, ct0, clen);  // 4 units per wave
+  else if (ns == 3) hipLaunchKernelGGL((k_mix<3>), dim3(blocks), dim3(64), 0, st, jobs, njobs, ct0, clen);
   else return 1;
   return hipGetLastError() != hipSuccess;
 }

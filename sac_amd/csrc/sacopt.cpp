@@ -14,6 +14,7 @@
 #include <cstring>
 #include <cstdlib>
 #include <map>
+#include <unordered_map>
 #include <functional>
 #include <string>
 #include <vector>
@@ -23,7 +24,7 @@
 
 extern "C" {
 int sacopt_lms_state_doubles(int S, int D);
-int sacopt_launch_lms(int S, int D, const LmsJob *jobs, int njobs, const uint16_t *tab, int bits, hipStream_t st, int limit);
+int sacopt_launch_lms(int S, int D, const LmsJob *jobs, int njobs, const uint16_t *tab, int bits, hipStream_t st, int limit, int ct0, int clen);
 int sacopt_lms_variant(int S, int D, int njobs, int bits, int limit);
 // (1280,640) stage: k_lms1c gives a chain two CUs (4.85k cycles per sample against 7.74k for both channels on one CU): taken
 // for up to 20 chains per launch. Beyond that a call is throughput-bound and the two-channel kernel is cheaper per CU. (A window
@@ -32,7 +33,7 @@ int sacopt_lms_variant(int S, int D, int njobs, int bits, int limit);
 #define L1C_WINDOW 20
 int sacopt_launch_lpc3(const LpcJob *jobs, int njobs, int max_n, int ols_n, hipStream_t st);
 int sacopt_launch_lpc2(const LpcJob *jobs, int njobs, int max_n, hipStream_t st);
-int sacopt_launch_mix(int ns, const MixJob *jobs, int njobs, hipStream_t st);
+int sacopt_launch_mix(int ns, const MixJob *jobs, int njobs, hipStream_t st, int ct0, int clen);
 int sacopt_launch_cost(const CostJob *jobs, int njobs, const int *pow2_bits, hipStream_t st);
 int sacopt_launch_cost_par(const CostJob *jobs, int njobs, int nbuf, const int *pow2_bits, hipStream_t st);
 int sacopt_launch_meanrms(const int32_t *e, int n, double *out, hipStream_t st);
@@ -49,6 +50,15 @@ int sacopt_noalloc_scratch(int device, void **ptr, size_t *stage_bytes, size_t *
 int sacopt_launch_cost_noalloc(const int32_t *e, int n, double *ctl, const int *pow2_bits, hipStream_t st);
 }
 
+#ifdef SACOPT_HOSTPROF  // timing builds: host time per section to stderr (tools/ only)
+#include <chrono>
+static double hp_now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+#define HP_MARK(var) const double var = hp_now()
+#define HP_PRINT(...) fprintf(stderr, __VA_ARGS__)
+#else
+#define HP_MARK(var)
+#define HP_PRINT(...)
+#endif
 static thread_local std::string g_create_error;  // error text of a failed sacopt_create on THIS thread
 // sacopt_cost_golomb_noalloc: every context on a GPU shares that GPU's static scratch. A call that finds the scratch in use
 // (another context / thread on the same GPU) returns an error instead of racing on it.
@@ -583,13 +593,28 @@ struct Chain {
   double coefs[SACOPT_MAX_COEFS];
   StageBuf sb[6];
 };
-typedef std::map<std::string, StageBuf> Memo;
+// Memo key: (frame, stage, the coefficient prefix that determines the stage's output, as bits: -0. and 0. are different keys,
+// which only costs a recomputation). Hashed: the optimizer of a 75-frame call looks up ~5 000 keys per round in a table that
+// grows to ~38 000 entries, and the host time between two rounds is GPU idle time.
+struct MemoKey {
+  int32_t frame, stage;
+  uint64_t c[SACOPT_MAX_COEFS];
+  bool operator==(const MemoKey &o) const { return frame == o.frame && stage == o.stage && memcmp(c, o.c, sizeof(c)) == 0; }
+};
+struct MemoHash {
+  size_t operator()(const MemoKey &k) const {
+    uint64_t h = 1469598103934665603ull ^ ((uint64_t)(uint32_t)k.frame << 32 | (uint32_t)k.stage);
+    for (int i = 0; i < SACOPT_MAX_COEFS; i++) { h ^= k.c[i]; h *= 1099511628211ull; h ^= h >> 29; }
+    return (size_t)h;
+  }
+};
+typedef std::unordered_map<MemoKey, StageBuf, MemoHash> Memo;
 
-static std::string memo_key(int frame, int stage, const double *coefs, int ncoef) {
-  std::string k(sizeof(int) * 2 + sizeof(double) * ncoef, '\0');
-  memcpy(&k[0], &frame, sizeof(int));
-  memcpy(&k[sizeof(int)], &stage, sizeof(int));
-  memcpy(&k[2 * sizeof(int)], coefs, sizeof(double) * ncoef);
+static MemoKey memo_key(int frame, int stage, const double *coefs, int ncoef) {
+  MemoKey k;
+  k.frame = frame; k.stage = stage;
+  for (int i = 0; i < SACOPT_MAX_COEFS; i++) k.c[i] = 0;
+  memcpy(k.c, coefs, sizeof(double) * ncoef);
   return k;
 }
 
@@ -653,11 +678,12 @@ static int eval_chains(sacopt_ctx *c, const ProfDesc &pd, const std::vector<DevF
                        Memo &memo) {
   const int nstage = (pd.type == SACOPT_PROFILE_FAST) ? 1 : pd.nlms + 2;
   std::vector<std::vector<int>> todo_s(nstage);
+  HP_MARK(hp0);
   for (int s = 0; s < nstage; s++) {
     std::vector<int> todo;  // chain indices that own a new buffer at this stage
     for (size_t ci = 0; ci < chains.size(); ci++) {
       Chain &ch = chains[ci];
-      const std::string key = memo_key(ch.frame, s, ch.coefs, pd.nprefix[s]);
+      const MemoKey key = memo_key(ch.frame, s, ch.coefs, pd.nprefix[s]);
       auto it = memo.find(key);
       if (it != memo.end()) { ch.sb[s] = it->second; continue; }
       const int n = fr[ch.frame].n;
@@ -759,72 +785,69 @@ static int eval_chains(sacopt_ctx *c, const ProfDesc &pd, const std::vector<DevF
       }
     }
   hipEvent_t ev_join = nullptr;
-  // ---- job tables of every stage and chunk: built first, one upload on c->st (a copy per table and chunk sat between the
-  // lead stage's launches: ~0.1 ms per chunk on the round's critical path)
+  // ---- ONE job table per stage, describing every chain's whole window; a chunk launch gets its span [t0, t0 + chunk) as kernel
+  // arguments (jobs.h: LMS_SPAN) and clips it to each chain's window. (A table per stage AND chunk was 5.4 MB per round of a 75-frame
+  // call: 3.5 ms of host time between two rounds -- GPU idle time -- to build and send it.)
   Stager stg;
-  std::vector<std::vector<size_t>> o_jobs(nchunk, std::vector<size_t>(nstage, 0));
-  std::vector<std::vector<int>> n_jobs_all(nchunk, std::vector<int>(nstage, 0));
+  std::vector<size_t> o_jobs(nstage, 0);
+  std::vector<int> n_jobs(nstage, 0);
   std::vector<long long> units_all(nchunk, 0);
-  for (int k = 0; k < nchunk; k++) {
-    const int t0 = k * chunk;
-    std::vector<int> &n_jobs = n_jobs_all[k];
-    long long &units = units_all[k];
-    for (int s = lead; s < nstage; s++) {
-      if (s <= pd.nlms) {
-        const StageDesc &sd = pd.lms[s - 1];
-        std::vector<LmsJob> jobs;
-        for (size_t q = 0; q < todo_s[s].size(); q++) {
-          const Chain &ch = chains[todo_s[s][q]];
-          const int n = fr[ch.frame].n;
-          if (t0 >= n && k != 0) continue;
-          LmsJob j;
-          for (int h = 0; h < 2; h++) { j.x[h] = ch.sb[s - 1].xn[h]; j.p[h] = ch.sb[s].p[h]; j.xn[h] = ch.sb[s].xn[h]; }
-          j.mu1 = ch.coefs[sd.c1];
-          j.mu2 = ch.coefs[sd.c2];
-          j.t0 = t0;
-          j.n = n - t0 < chunk ? (n - t0 > 0 ? n - t0 : 0) : chunk;
-          j.state = carry ? state[s][q] : nullptr;
-          jobs.push_back(j);
-          if (s == 1) units += j.n;
-        }
-        n_jobs[s] = (int)jobs.size();
-        o_jobs[k][s] = stg.add(jobs.data(), jobs.size() * sizeof(LmsJob));
-      } else {
-        std::vector<MixJob> jobs;
-        for (size_t q = 0; q < todo_s[s].size(); q++) {
-          const Chain &ch = chains[todo_s[s][q]];
-          const DevFrame &f = fr[ch.frame];
-          if (t0 >= f.n && k != 0) continue;
-          MixJob j;
-          memset(&j, 0, sizeof(j));
-          for (int h = 0; h < 2; h++) {
-            j.s[h] = f.s[h] + f.from;
-            j.p0[h] = ch.sb[0].p[h];
-            j.x1[h] = ch.sb[0].xn[h];
-            for (int q2 = 0; q2 < pd.nlms; q2++) j.pk[q2][h] = ch.sb[q2 + 1].p[h];
-            j.e[h] = ch.sb[s].e[h];
-            j.u[h] = ch.sb[s].u[h];
-          }
-          j.umax = ch.sb[s].umax;
-          j.alpha = ch.coefs[pd.cmix];
-          j.t0 = t0;
-          j.n = f.n - t0 < chunk ? (f.n - t0 > 0 ? f.n - t0 : 0) : chunk;
-          j.state = carry ? state[s][q] : nullptr;
-          jobs.push_back(j);
-        }
-        n_jobs[s] = (int)jobs.size();
-        o_jobs[k][s] = stg.add(jobs.data(), jobs.size() * sizeof(MixJob));
+  for (int s = lead; s < nstage; s++) {
+    if (s <= pd.nlms) {
+      const StageDesc &sd = pd.lms[s - 1];
+      std::vector<LmsJob> jobs;
+      for (size_t q = 0; q < todo_s[s].size(); q++) {
+        const Chain &ch = chains[todo_s[s][q]];
+        const int n = fr[ch.frame].n;
+        LmsJob j;
+        for (int h = 0; h < 2; h++) { j.x[h] = ch.sb[s - 1].xn[h]; j.p[h] = ch.sb[s].p[h]; j.xn[h] = ch.sb[s].xn[h]; }
+        j.mu1 = ch.coefs[sd.c1];
+        j.mu2 = ch.coefs[sd.c2];
+        j.t0 = 0;
+        j.n = n;
+        j.state = carry ? state[s][q] : nullptr;
+        jobs.push_back(j);
+        if (s == 1)
+          for (int k = 0; k < nchunk; k++) { const int r = n - k * chunk; units_all[k] += r < 0 ? 0 : (r < chunk ? r : chunk); }
       }
+      n_jobs[s] = (int)jobs.size();
+      o_jobs[s] = stg.add(jobs.data(), jobs.size() * sizeof(LmsJob));
+    } else {
+      std::vector<MixJob> jobs;
+      for (size_t q = 0; q < todo_s[s].size(); q++) {
+        const Chain &ch = chains[todo_s[s][q]];
+        const DevFrame &f = fr[ch.frame];
+        MixJob j;
+        memset(&j, 0, sizeof(j));
+        for (int h = 0; h < 2; h++) {
+          j.s[h] = f.s[h] + f.from;
+          j.p0[h] = ch.sb[0].p[h];
+          j.x1[h] = ch.sb[0].xn[h];
+          for (int q2 = 0; q2 < pd.nlms; q2++) j.pk[q2][h] = ch.sb[q2 + 1].p[h];
+          j.e[h] = ch.sb[s].e[h];
+          j.u[h] = ch.sb[s].u[h];
+        }
+        j.umax = ch.sb[s].umax;
+        j.alpha = ch.coefs[pd.cmix];
+        j.t0 = 0;
+        j.n = f.n;
+        j.state = carry ? state[s][q] : nullptr;
+        jobs.push_back(j);
+      }
+      n_jobs[s] = (int)jobs.size();
+      o_jobs[s] = stg.add(jobs.data(), jobs.size() * sizeof(MixJob));
     }
   }
   char *d_tables = arena_alloc<char>(c, stg.host.size() + 256);
   if (!d_tables) { c->err = "device arena exhausted"; return 1; }
+  HP_MARK(hp1);
   if (upload_bytes(c, d_tables, stg.host.data(), stg.host.size(), c->st)) return 1;
+  HP_MARK(hp2);
+  std::vector<void *> d_jobs(nstage, nullptr);
+  for (int s = lead; s < nstage; s++) d_jobs[s] = d_tables + o_jobs[s];
   for (int k = 0; k < nchunk; k++) {
-    std::vector<void *> d_jobs(nstage, nullptr);
-    for (int s = lead; s < nstage; s++) d_jobs[s] = d_tables + o_jobs[k][s];
-    const std::vector<int> &n_jobs = n_jobs_all[k];
     const long long units = units_all[k];
+    const int ct0 = k * chunk, clen = carry ? chunk : 0;  // (a single launch covers the jobs' own spans)
     // ---- launches: lead stage on c->st, the first follower on c->sC, the others on c->sE, each behind an event: three
     // pipeline stages per chunk (one follower stream ran (32,16), (8,4) and the mixer of a chunk back to back, as long as
     // an lms2 lead chunk: the followers fell behind and left a tail of three chunks after the lead's last one)
@@ -841,14 +864,14 @@ static int eval_chains(sacopt_ctx *c, const ProfDesc &pd, const std::vector<DevF
             TAKE_EVENT(c, b, true);
             HIPCK(c, hipEventRecord(a, st));
           }
-          if (sacopt_launch_lms(sd.S, sd.D, (const LmsJob *)d_jobs[s], n_jobs[s], c->d_tab, c->bits, st, L1C_WINDOW)) { c->err = "k_lms launch failed"; return 1; }
+          if (sacopt_launch_lms(sd.S, sd.D, (const LmsJob *)d_jobs[s], n_jobs[s], c->d_tab, c->bits, st, L1C_WINDOW, ct0, clen)) { c->err = "k_lms launch failed"; return 1; }
           if (dominant) {
             HIPCK(c, hipEventRecord(b, st));
             c->lms_ev.push_back({a, b});
             c->lms_units += units;
           }
         } else {
-          if (sacopt_launch_mix(pd.nlms, (const MixJob *)d_jobs[s], n_jobs[s], st)) { c->err = "k_mix launch failed"; return 1; }
+          if (sacopt_launch_mix(pd.nlms, (const MixJob *)d_jobs[s], n_jobs[s], st, ct0, clen)) { c->err = "k_mix launch failed"; return 1; }
         }
       }
       if (s == lead && lead < nstage - 1) {
@@ -871,6 +894,8 @@ static int eval_chains(sacopt_ctx *c, const ProfDesc &pd, const std::vector<DevF
     HIPCK(c, hipEventRecord(ev_join, lasts));
     HIPCK(c, hipStreamWaitEvent(c->st, ev_join, 0));
   }
+  HP_MARK(hp3);
+  HP_PRINT("eval_chains: %zu chains, build %.2f ms, upload %.2f ms (%zu bytes), launches %.2f ms\n", chains.size(), hp1 - hp0, hp2 - hp1, stg.host.size(), hp3 - hp2);
   return 0;
 }
 
@@ -1080,7 +1105,7 @@ static int final_pass_enqueue(sacopt_ctx *c, const ProfDesc &pd, const std::vect
       TAKE_EVENT(c, b, true);
       HIPCK(c, hipEventRecord(a, sLead));
     }
-    if (sacopt_launch_lms(pd.lms[0].S, pd.lms[0].D, d_lms[0][k], n_lms[0][k], c->d_tab, c->bits, sLead, L1C_FRAMES)) { c->err = "k_lms launch failed"; return 1; }
+    if (sacopt_launch_lms(pd.lms[0].S, pd.lms[0].D, d_lms[0][k], n_lms[0][k], c->d_tab, c->bits, sLead, L1C_FRAMES, 0, 0)) { c->err = "k_lms launch failed"; return 1; }
     if (dominant) {
       HIPCK(c, hipEventRecord(b, sLead));
       c->lms_ev.push_back({a, b});
@@ -1093,7 +1118,7 @@ static int final_pass_enqueue(sacopt_ctx *c, const ProfDesc &pd, const std::vect
     // followers of chunk k together take no longer than the lead stage of chunk k+1
     hipStream_t fs = c->sB;
     for (int q = 1; q < pd.nlms; q++) {
-      if (sacopt_launch_lms(pd.lms[q].S, pd.lms[q].D, d_lms[q][k], n_lms[q][k], c->d_tab, c->bits, fs, L1C_FRAMES)) { c->err = "k_lms launch failed"; return 1; }
+      if (sacopt_launch_lms(pd.lms[q].S, pd.lms[q].D, d_lms[q][k], n_lms[q][k], c->d_tab, c->bits, fs, L1C_FRAMES, 0, 0)) { c->err = "k_lms launch failed"; return 1; }
       if (q == 1 && c->sD) {
         hipEvent_t e2;
         if (new_event(&e2)) return 1;
@@ -1104,7 +1129,7 @@ static int final_pass_enqueue(sacopt_ctx *c, const ProfDesc &pd, const std::vect
       }
     }
     if (!c->sD && lpc_chunk(k + 2)) return 1;
-    if (sacopt_launch_mix(pd.nlms, d_mix[k], n_mix[k], fs)) { c->err = "k_mix launch failed"; return 1; }
+    if (sacopt_launch_mix(pd.nlms, d_mix[k], n_mix[k], fs, 0, 0)) { c->err = "k_mix launch failed"; return 1; }
     last_stream = fs;
   }
   if (new_event(done)) return 1;
@@ -1495,6 +1520,7 @@ static int optimize_core(sacopt_ctx *c, const ProfDesc &pd, const std::vector<De
   std::vector<double> best_cost(nframes);
   std::vector<int> rows(nframes, 0);
   Memo memo;
+  memo.reserve((size_t)nframes * 96 * 6);  // every candidate's stage outputs stay memoised for the whole search
   auto add_row = [&](int f, double coef, double x, double cost) {
     if (trace && rows[f] < max_rows) {
       double *r = trace + ((size_t)f * max_rows + rows[f]) * 3;
@@ -1519,10 +1545,14 @@ static int optimize_core(sacopt_ctx *c, const ProfDesc &pd, const std::vector<De
         memcpy(ch.coefs, cur[f].data(), 8 * pd.ncoef);
         if (k >= nb) ch.coefs[i] = grid[i][k - nb];
       }
+    HP_MARK(hpa);
     if (eval_chains(c, pd, fr, chains, memo)) return 1;
     if (!base_done && after_first && after_first()) return 1;
     std::vector<double> costs;
+    HP_MARK(hpb);
     if (cost_round(c, pd, fr, chains, tot, d_state, costs)) return 1;
+    HP_MARK(hpc);
+    HP_PRINT("round %d: eval_chains (+ full-frame enqueue) %.2f ms, cost_round incl. wait %.2f ms\n", i, hpb - hpa, hpc - hpb);
     for (int f = 0; f < nframes; f++) {
       if (nb) { best_cost[f] = costs[(size_t)f * tot]; add_row(f, -1, cur[f][0], best_cost[f]); }
       if (!nc) continue;
@@ -1898,7 +1928,7 @@ extern "C" int sacopt_lms_pair(sacopt_ctx *c, int S, int D, double mu1, double m
   TAKE_EVENT(c, a, true);
   TAKE_EVENT(c, b, true);
   HIPCK(c, hipEventRecord(a, c->st));
-  if (sacopt_launch_lms(S, D, dj, (int)jobs.size(), c->d_tab, c->bits | sw, c->st, L1C_FRAMES)) { c->err = "unsupported (S,D) or launch failure"; return 1; }
+  if (sacopt_launch_lms(S, D, dj, (int)jobs.size(), c->d_tab, c->bits | sw, c->st, L1C_FRAMES, 0, 0)) { c->err = "unsupported (S,D) or launch failure"; return 1; }
   HIPCK(c, hipEventRecord(b, c->st));
   c->lms_ev.push_back({a, b});
   if (copy_out(c, p0, j.p[0], (size_t)n * 8) || copy_out(c, p1, j.p[1], (size_t)n * 8)) return 1;
@@ -1970,7 +2000,7 @@ extern "C" int sacopt_rls_run(sacopt_ctx *c, int nst, double alpha, const double
     std::vector<MixJob> jobs = {j};
     MixJob *dj;
     if (upload(c, jobs, &dj)) return 1;
-    if (sacopt_launch_mix(nst, dj, 1, c->st)) { c->err = "k_mix launch failed"; return 1; }
+    if (sacopt_launch_mix(nst, dj, 1, c->st, 0, 0)) { c->err = "k_mix launch failed"; return 1; }
   }
   if (copy_out(c, p, dp, (size_t)len * 8)) return 1;
   return end_timing(c);
