@@ -24,6 +24,12 @@
 #define BP_NC2 258   // bpn2[0], bpn2[1 + ctx1]: indices < 257
 #define BP_NW 42     // lmixref[8][3], lmixsig[8][2], finalmix[2]  (mixctx = state & 7: 8 of the 32 mixers are ever used)
 #define BP_DIVN 1024 // div_tbl entries reachable with the coder's counter limit (1000)
+#ifndef BP_WPC_MAX
+#define BP_WPC_MAX 2048  // ... and up to this many the wave-per-coder form (8 coders per workgroup: one workgroup per CU, 256 CUs)
+#endif
+#ifndef BP_LAT_MAX
+#define BP_LAT_MAX 4096  // passes of up to this many buffers use the latency form of k_bpsize (8 coders per wave)
+#endif
 
 struct BpJob {
   const int32_t *buf;  // s2u residuals (non-negative), n entries
@@ -53,36 +59,62 @@ struct BpTables {
   const uint16_t *sse_init;
   int tscale, xscale;
 };
-
-__global__ __launch_bounds__(64) void k_bpsize(const BpJob *__restrict__ jobs, int nbuf, int maxn, int maxplanes, const int32_t *__restrict__ T,
+// LPW = coders (lanes) per wave.
+//   64  throughput form: every lane a coder; the SSE maps ((maxbpn+1) x 32 contexts x 264 bytes per coder) live in HBM.
+//   8   latency form, for passes with few buffers (an optimizer round: candidates x channels x frames): the chip has more CUs than
+//       such a pass has waves, so what counts is the time per decision of ONE coder. Eight coders per wave leave room for the SSE
+//       maps in LDS -- a plane's contexts ((bpn << 5) + msb, vle.cpp:98) are touched in that plane only, so ONE plane's maps
+//       (32 contexts x 2 x 33 bins) are enough and are simply re-initialised per plane: no HBM access in the decision chain at
+//       all (the dependent L2 round trip per decision was ~1 us of 2.9) -- and residuals / msb values are fetched 24 samples
+//       ahead through a small LDS ring (the msb value of sample s+4 used to be a global load in front of every decision).
+//   WPC (with LPW = 8): a WAVE per coder instead of a lane -- 8 waves per workgroup, every lane of a wave computes the same coder
+//       (LDS reads broadcast, stores coincide). A wave then runs only the code path its coder takes (lanes that hold different
+//       coders execute PredictRef AND PredictSig, masked) and the eight coders' dependent chains interleave on the four SIMDs.
+template <int LPW, bool WPC = false>
+__global__ __launch_bounds__(WPC ? 64 * LPW : 64) void k_bpsize(const BpJob *__restrict__ jobs, int nbuf, int maxn, int maxplanes, const int32_t *__restrict__ T,
                                                uint8_t *__restrict__ msb_g, uint32_t *__restrict__ sse_g, uint8_t *__restrict__ lb_g,
                                                BpTables tb, int32_t *__restrict__ sizes) {
+  constexpr bool LAT = LPW < 64;
+  constexpr int SSE_PLANE = 32 * 2 * 33;  // entries of one plane's SSE maps per coder
   __shared__ int16_t fwd[BP_PSCALE];
   __shared__ uint16_t inv[1 << BP_DBITS];
   __shared__ uint16_t divt[BP_DIVN];
-  __shared__ uint16_t c1[BP_NC1][64], c2[BP_NC2][64];
-  __shared__ int wts[BP_NW][64];
-  __shared__ uint32_t lbm[32][64];  // SSENL::lb of context (bpn << 5) + msb: bit msb of word [bpn][lane] (a global byte per context was a
-                                    // dependent L2 round trip in front of the map entries' addresses)
-  const int lane = threadIdx.x, blk = blockIdx.x, b = blk * 64 + lane;
-  for (int i = lane; i < BP_PSCALE; i += 64) fwd[i] = tb.fwd[i];
-  for (int i = lane; i < (1 << BP_DBITS); i += 64) inv[i] = tb.inv[i];
-  for (int i = lane; i < BP_DIVN; i += 64) divt[i] = (uint16_t)(BP_PSCALE / (i + 3));  // counter.h:38-50
-  for (int i = 0; i < BP_NC1; i++) c1[i][lane] = BP_PSCALE >> 1;
-  for (int i = 0; i < BP_NC2; i++) c2[i][lane] = BP_PSCALE >> 1;
-  for (int i = 0; i < BP_NW; i++) wts[i][lane] = 0;  // NMixLogistic::Init(0)
-  for (int i = 0; i < 32; i++) lbm[i][lane] = 0;
-  const bool live = b < nbuf;
+  __shared__ uint16_t c1[BP_NC1][LPW], c2[BP_NC2][LPW];
+  __shared__ int wts[BP_NW][LPW];
+  __shared__ uint32_t lbm[LAT ? 1 : 32][LPW];  // SSENL::lb of context (bpn << 5) + msb: bit msb of word [bpn][lane] (LAT: a register per plane)
+  __shared__ uint32_t ssel[LAT ? SSE_PLANE : 1][LPW];  // LAT: the current plane's SSE maps, [(msb * 2 + lb) * 33 + q][lane]: p1 | counter << 16
+  __shared__ int32_t rT[LAT ? 32 : 1][LPW];            // LAT: prefetch rings, slot = sample index & 31
+  __shared__ uint8_t rM[LAT ? 32 : 1][LPW];
+  constexpr int NTH = WPC ? 64 * LPW : 64;  // threads of the workgroup
+  const int lane = threadIdx.x, blk = blockIdx.x;
+  const int col = WPC ? (int)(threadIdx.x >> 6) : lane;  // this thread's coder within the workgroup
+  const int b = blk * LPW + col;
+  const bool act = col < LPW;
+  const int ln = act ? col : 0;  // (idle lanes of the latency form address column 0 and never store)
+  const bool wr = !WPC || (threadIdx.x & 63) == 0;  // the one thread of a coder that stores to HBM
+  for (int i = lane; i < BP_PSCALE; i += NTH) fwd[i] = tb.fwd[i];
+  for (int i = lane; i < (1 << BP_DBITS); i += NTH) inv[i] = tb.inv[i];
+  for (int i = lane; i < BP_DIVN; i += NTH) divt[i] = (uint16_t)(BP_PSCALE / (i + 3));  // counter.h:38-50
+  for (int i = lane; i < BP_NC1 * LPW; i += NTH) (&c1[0][0])[i] = BP_PSCALE >> 1;
+  for (int i = lane; i < BP_NC2 * LPW; i += NTH) (&c2[0][0])[i] = BP_PSCALE >> 1;
+  for (int i = lane; i < BP_NW * LPW; i += NTH) (&wts[0][0])[i] = 0;  // NMixLogistic::Init(0)
+  if (!LAT) for (int i = 0; i < 32; i++) lbm[i][ln] = 0;
+  const bool live = act && b < nbuf;
   const int n = live ? jobs[b].n : 0, mbp = live ? jobs[b].maxbpn : -1;
-  const int32_t *Tb = T + (size_t)blk * maxn * 64 + lane;
-  uint8_t *msb = msb_g + (size_t)blk * (maxn + 16) * 64 + lane;       // [s + 4][lane]: zero entries on either side
+  // scratch is laid out per 64 buffers whatever LPW is: buffer b -> block b / 64, column b % 64
+  const int32_t *Tb = T + (size_t)(b >> 6) * maxn * 64 + (b & 63);
+  uint8_t *msb = msb_g + (size_t)(b >> 6) * (maxn + 16) * 64 + (b & 63);       // [s + 4][lane]: zero entries on either side
   const int nctx = maxplanes * 32;
-  uint32_t *sse = sse_g + (size_t)blk * nctx * 66 * 64 + lane;         // [(ctx * 2 + lb) * 33 + q][lane]: p1 | counter << 16
+  uint32_t *sse = sse_g + (size_t)blk * nctx * 66 * 64 + lane;         // (LPW = 64) [(ctx * 2 + lb) * 33 + q][lane]: p1 | counter << 16
   (void)lb_g;
-  for (int s = 0; s < maxn + 16; s++) msb[(size_t)s * 64] = 0;
-  for (int e = 0; e < nctx * 66; e++) sse[(size_t)e * 64] = tb.sse_init[e % 33];  // SSENL ctor, sse.h:94-105
+  if (WPC) { if (live) for (int s = (int)(threadIdx.x & 63); s < maxn + 16; s += 64) msb[(size_t)s * 64] = 0; }
+  else if (live || !LAT) for (int s = 0; s < maxn + 16; s++) msb[(size_t)s * 64] = 0;
+  if (!LAT) for (int e = 0; e < nctx * 66; e++) sse[(size_t)e * 64] = tb.sse_init[e % 33];  // SSENL ctor, sse.h:94-105
   __syncthreads();
   const int tscale = tb.tscale, xscale = tb.xscale;
+  // x / xscale for 0 <= x < 2^23 by a multiplication: q = mulhi(x, ceil(2^32 / xscale)) is the quotient or one more
+  const uint32_t xmagic = (uint32_t)((0x100000000ull + (uint32_t)xscale - 1) / (uint32_t)xscale);
+  auto divx = [&](int x) -> int { int q = (int)__umulhi((uint32_t)x, xmagic); q -= (q * xscale > x) ? 1 : 0; return q; };
 
   auto dinv = [&](int x) -> int { return x < -(1 << (BP_DBITS - 1)) ? 0 : (x > (1 << (BP_DBITS - 1)) - 1 ? BP_PSCALE - 1 : (int)inv[x + (1 << (BP_DBITS - 1))]); };
   auto lc16 = [&](uint16_t *c, int bit, int L) {  // LinearCounter16::update(bit, L), counter.h:30-35
@@ -109,28 +141,57 @@ __global__ __launch_bounds__(64) void k_bpsize(const BpJob *__restrict__ jobs, i
   };
   (void)cache;
 
-  int topbpn = mbp;  // the wave walks the planes of its deepest buffer; a lane joins at its own maxbpn
-  for (int o = 32; o; o >>= 1) topbpn = max(topbpn, __shfl_xor(topbpn, o));
+  int topbpn = mbp;  // the workgroup walks the planes of its deepest buffer; a coder joins at its own maxbpn
   int topn = n;
-  for (int o = 32; o; o >>= 1) topn = max(topn, __shfl_xor(topn, o));
+  if constexpr (WPC) {  // (the plane loop holds workgroup barriers: its bounds are the same in every wave)
+    for (int k = 0; k < LPW; k++)
+      if (blk * LPW + k < nbuf) { topbpn = max(topbpn, jobs[blk * LPW + k].maxbpn); topn = max(topn, jobs[blk * LPW + k].n); }
+  } else {
+    for (int o = 32; o; o >>= 1) topbpn = max(topbpn, __shfl_xor(topbpn, o));
+    for (int o = 32; o; o >>= 1) topn = max(topn, __shfl_xor(topn, o));
+  }
+  // LAT: entry idx of the residuals / of the msb array (which has maxn + 16 rows), 0 beyond the ends
+  auto gT = [&](int idx) -> int32_t { return (live && idx < topn) ? Tb[(size_t)idx * 64] : 0; };
+  auto gM = [&](int idx) -> uint8_t { return (live && idx < maxn + 16) ? msb[(size_t)idx * 64] : (uint8_t)0; };
   for (int bpn = topbpn; bpn >= 0; bpn--) {
     const bool plane_on = live && bpn <= mbp;
-    uint32_t state = 0;
+    uint32_t state = 0, lbreg = 0;
+    if constexpr (LAT) {  // this plane's SSE maps start from the constructor's values (sse.h:94-105); the rings from sample 0
+      __syncthreads();
+      for (int e = lane; e < SSE_PLANE * LPW; e += NTH) (&ssel[0][0])[e] = tb.sse_init[(e / LPW) % 33];
+      if (act)
+        for (int k = 0; k < 24; k++) { rT[k][ln] = gT(k); rM[k][ln] = gM(k); }
+      __syncthreads();
+    }
     // sliding windows: residuals s-2..s+2, msb s-4..s+4 (the entries beyond the buffer's ends read as 0: vle.cpp:19-28, :36-39)
     int a_m2 = 0, a_m1 = 0, a_0 = 0, a_p1 = 0, a_p2 = 0;
     int m[9];
 #pragma unroll
     for (int k = 0; k < 9; k++) m[k] = 0;
-    if (topn > 0) { a_0 = Tb[0]; a_p1 = topn > 1 ? Tb[64] : 0; a_p2 = topn > 2 ? Tb[128] : 0; }
+    if constexpr (LAT) {
+      a_0 = rT[0][ln]; a_p1 = rT[1][ln]; a_p2 = rT[2][ln];
 #pragma unroll
-    for (int k = 4; k < 9; k++) m[k] = msb[(size_t)(k) * 64];  // m[4] = msb[s = 0] ... m[8] = msb[s = 4]
-    for (int s = 0; s < topn; s++) {
+      for (int k = 4; k < 9; k++) m[k] = rM[k][ln];
+    } else {
+      if (topn > 0) { a_0 = Tb[0]; a_p1 = topn > 1 ? Tb[64] : 0; a_p2 = topn > 2 ? Tb[128] : 0; }
+#pragma unroll
+      for (int k = 4; k < 9; k++) m[k] = msb[(size_t)(k) * 64];  // m[4] = msb[s = 0] ... m[8] = msb[s = 4]
+    }
+    for (int s0 = 0; s0 < topn; s0 += (LAT ? 8 : topn)) {
+    int32_t pT[LAT ? 8 : 1];
+    uint8_t pM[LAT ? 8 : 1];
+    if constexpr (LAT) {  // entries s0 + 24 .. s0 + 31 of both arrays: issued here, in the rings eight decisions later
+#pragma unroll
+      for (int k = 0; k < 8; k++) { pT[k] = gT(s0 + 24 + k); pM[k] = gM(s0 + 24 + k); }
+    }
+    const int send = LAT ? min(s0 + 8, topn) : topn;
+    for (int s = s0; s < send; s++) {
       if (plane_on && s < n) {
         const int bit = (a_0 >> bpn) & 1;
         const int mixctx = (int)(state & 7);
         const int mymsb = m[4];
         const bool sig = mymsb != 0;
-        uint16_t *pc0 = &c2[0][lane], *pc1, *pc2 = nullptr;
+        uint16_t *pc0 = &c2[0][ln], *pc1, *pc2 = nullptr;
         int *w;
         int nin;
         if (sig) {  // PredictRef, vle.cpp:32-60
@@ -142,9 +203,9 @@ __global__ __launch_bounds__(64) void k_bpsize(const BpJob *__restrict__ jobs, i
           if ((nval >> (bpn + 1)) > tval) lctx += 2;
           if ((lval2 >> bpn) > tval1) lctx += 4;
           if ((nval2 >> (bpn + 1)) > tval) lctx += 8;
-          pc1 = &c1[1 + mymsb][lane];
-          pc2 = &c1[1 + 32 + lctx][lane];
-          w = &wts[mixctx * 3][lane];
+          pc1 = &c1[1 + mymsb][ln];
+          pc2 = &c1[1 + 32 + lctx][ln];
+          w = &wts[mixctx * 3][ln];
           nin = 3;
         } else {  // PredictSig, vle.cpp:71-92
           int ctx1 = 0;
@@ -156,28 +217,30 @@ __global__ __launch_bounds__(64) void k_bpsize(const BpJob *__restrict__ jobs, i
           if (m[7] && s + 3 <= n - 1) ctx1 += 32;
           if (m[0]) ctx1 += 64;
           if (m[8] && s + 4 <= n - 1) ctx1 += 128;
-          pc1 = &c2[1 + ctx1][lane];
-          w = &wts[24 + mixctx * 2][lane];
+          pc1 = &c2[1 + ctx1][ln];
+          w = &wts[24 + mixctx * 2][ln];
           nin = 2;
         }
+        (void)nin;
         // NMixLogistic::Predict, mixer.h:73-84
         const int x0 = fwd[*pc0], x1 = fwd[*pc1], x2 = sig ? (int)fwd[*pc2] : 0;
-        long long sum = (long long)(w[0] * x0) + (long long)(w[64] * x1);
-        if (sig) sum += (long long)(w[128] * x2);
+        long long sum = (long long)(w[0] * x0) + (long long)(w[LPW] * x1);
+        if (sig) sum += (long long)(w[2 * LPW] * x2);
         const int pd = bp_clamp(dinv((int)bp_idiv64(sum, BP_WBITS)), 1, BP_PSCALEm);
         // SSENL::Predict, sse.h:106-118  (context (bpn << 5) + msb, vle.cpp:98)
         const int ctx = (bpn << 5) + mymsb;
-        const int lb = (int)((lbm[bpn][lane] >> mymsb) & 1u);
+        const int lb = LAT ? (int)((lbreg >> mymsb) & 1u) : (int)((lbm[LAT ? 0 : bpn][ln] >> mymsb) & 1u);
         int pq = (int)fwd[pd] + tscale;
         pq = pq < 0 ? 0 : (pq > 2 * tscale ? 2 * tscale : pq);
-        const int q = pq / xscale, pmod = pq - q * xscale;
-        uint32_t *e0 = &sse[(size_t)((ctx * 2 + lb) * 33 + q) * 64], *e1 = e0 + 64;
+        const int q = divx(pq), pmod = pq - q * xscale;
+        uint32_t *e0 = LAT ? &ssel[(mymsb * 2 + lb) * 33 + q][ln] : &sse[(size_t)((ctx * 2 + lb) * 33 + q) * 64];
+        uint32_t *e1 = e0 + (LAT ? LPW : 64);
         const int pl = (int)(*e0 & 0xffffu), ph = (int)(*e1 & 0xffffu);
-        const int ps = bp_clamp((pl * (xscale - pmod) + ph * pmod) / xscale, 1, BP_PSCALEm);
+        const int ps = bp_clamp(divx(pl * (xscale - pmod) + ph * pmod), 1, BP_PSCALEm);
         // finalmix[0].Predict({sse, p1}), vle.cpp:100-102
-        int *wf = &wts[40][lane];
+        int *wf = &wts[40][ln];
         const int y0 = fwd[ps], y1 = fwd[pd];
-        const long long fs = (long long)(wf[0] * y0) + (long long)(wf[64] * y1);
+        const long long fs = (long long)(wf[0] * y0) + (long long)(wf[LPW] * y1);
         const int pf = bp_clamp(dinv((int)bp_idiv64(fs, BP_WBITS)), 1, BP_PSCALEm);
         // RangeCoderSH::EncodeBitOne, range.cpp:65-70
         const uint32_t rnew = (uint32_t)(((unsigned long long)range * ((uint32_t)(BP_PSCALE - pf) << (32 - BP_PBITS))) >> 32);
@@ -190,31 +253,44 @@ __global__ __launch_bounds__(64) void k_bpsize(const BpJob *__restrict__ jobs, i
         {
           const int err = (bit << BP_PBITS) - pd;
           w[0] = bp_clamp(w[0] + bp_idiv32(bp_idiv32(x0 * err, BP_DBITS) * 800, BP_DBITS), -BP_WRANGE, BP_WRANGE - 1);
-          w[64] = bp_clamp(w[64] + bp_idiv32(bp_idiv32(x1 * err, BP_DBITS) * 800, BP_DBITS), -BP_WRANGE, BP_WRANGE - 1);
-          if (sig) w[128] = bp_clamp(w[128] + bp_idiv32(bp_idiv32(x2 * err, BP_DBITS) * 800, BP_DBITS), -BP_WRANGE, BP_WRANGE - 1);
+          w[LPW] = bp_clamp(w[LPW] + bp_idiv32(bp_idiv32(x1 * err, BP_DBITS) * 800, BP_DBITS), -BP_WRANGE, BP_WRANGE - 1);
+          if (sig) w[2 * LPW] = bp_clamp(w[2 * LPW] + bp_idiv32(bp_idiv32(x2 * err, BP_DBITS) * 800, BP_DBITS), -BP_WRANGE, BP_WRANGE - 1);
         }
         state = (state << 1) + (sig ? 0u : 1u);
         // UpdateSSE (vle.cpp:104-108): both bins at limit 1000, lb = bit; final mixer at 300
         lcl(e0, bit, 1000);
         lcl(e1, bit, 1000);
-        lbm[bpn][lane] = (lbm[bpn][lane] & ~(1u << mymsb)) | ((uint32_t)bit << mymsb);
+        if constexpr (LAT) lbreg = (lbreg & ~(1u << mymsb)) | ((uint32_t)bit << mymsb);
+        else lbm[LAT ? 0 : bpn][ln] = (lbm[LAT ? 0 : bpn][ln] & ~(1u << mymsb)) | ((uint32_t)bit << mymsb);
         {
           const int err = (bit << BP_PBITS) - pf;
           wf[0] = bp_clamp(wf[0] + bp_idiv32(bp_idiv32(y0 * err, BP_DBITS) * 300, BP_DBITS), -BP_WRANGE, BP_WRANGE - 1);
-          wf[64] = bp_clamp(wf[64] + bp_idiv32(bp_idiv32(y1 * err, BP_DBITS) * 300, BP_DBITS), -BP_WRANGE, BP_WRANGE - 1);
+          wf[LPW] = bp_clamp(wf[LPW] + bp_idiv32(bp_idiv32(y1 * err, BP_DBITS) * 300, BP_DBITS), -BP_WRANGE, BP_WRANGE - 1);
         }
-        if (!sig && bit) { m[4] = bpn; msb[(size_t)(s + 4) * 64] = (uint8_t)bpn; }  // vle.cpp:132
+        if (!sig && bit) { m[4] = bpn; if (wr) msb[(size_t)(s + 4) * 64] = (uint8_t)bpn; }  // vle.cpp:132
       }
       // slide the windows
       a_m2 = a_m1; a_m1 = a_0; a_0 = a_p1; a_p1 = a_p2;
-      a_p2 = (s + 3 < topn) ? Tb[(size_t)(s + 3) * 64] : 0;
 #pragma unroll
       for (int k = 0; k < 8; k++) m[k] = m[k + 1];
-      m[8] = msb[(size_t)(s + 9) * 64];  // msb[s + 1 + 4], stored at [s + 5 + 4]; the array has 4 zero entries past maxn
+      if constexpr (LAT) {
+        a_p2 = rT[(s + 3) & 31][ln];
+        m[8] = rM[(s + 9) & 31][ln];
+      } else {
+        a_p2 = (s + 3 < topn) ? Tb[(size_t)(s + 3) * 64] : 0;
+        m[8] = msb[(size_t)(s + 9) * 64];  // msb[s + 1 + 4], stored at [s + 5 + 4]; the array has 4 zero entries past maxn
+      }
+    }
+    if constexpr (LAT) {
+      if (act) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) { rT[(s0 + 24 + k) & 31][ln] = pT[k]; rM[(s0 + 24 + k) & 31][ln] = pM[k]; }
+      }
+    }
     }
   }
   if (live) {
     for (int i = 0; i < 5; i++) shift_low();  // RangeCoderSH::Stop, range.cpp:60-63
-    sizes[b] = pos;
+    if (wr) sizes[b] = pos;
   }
 }

@@ -2349,7 +2349,11 @@ extern "C" int sacopt_launch_bpsize(const BpJob *jobs, int nbuf, int maxn, int m
   const int nblk = (nbuf + 63) / 64;
   if (maxn > 0) hipLaunchKernelGGL(k_bp_transpose, dim3((maxn + 255) / 256, nblk), dim3(256), 0, st, jobs, nbuf, maxn, T);
   BpTables tb = {fwd, inv, sse_init, tscale, xscale};
-  hipLaunchKernelGGL(k_bpsize, dim3(nblk), dim3(64), 0, st, jobs, nbuf, maxn, maxplanes, T, msb, sse, lb, tb, sizes);
+  // few buffers (an optimizer round, a clip's channels): eight coders per wave, everything a decision touches in LDS (bitplane.h);
+  // beyond 4096 buffers the chip could not hold all waves of that form at once and the 64-coder form moves more decisions per CU
+  if (nbuf <= BP_WPC_MAX) hipLaunchKernelGGL((k_bpsize<8, true>), dim3((nbuf + 7) / 8), dim3(512), 0, st, jobs, nbuf, maxn, maxplanes, T, msb, sse, lb, tb, sizes);
+  else if (nbuf <= BP_LAT_MAX) hipLaunchKernelGGL((k_bpsize<8>), dim3((nbuf + 7) / 8), dim3(64), 0, st, jobs, nbuf, maxn, maxplanes, T, msb, sse, lb, tb, sizes);
+  else hipLaunchKernelGGL((k_bpsize<64>), dim3(nblk), dim3(64), 0, st, jobs, nbuf, maxn, maxplanes, T, msb, sse, lb, tb, sizes);
   return hipGetLastError() != hipSuccess;
 }
 extern "C" int sacopt_launch_map(const MapJob *jobs, int njobs, int max_numsamples, int max_n, hipStream_t st) {
