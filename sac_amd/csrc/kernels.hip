@@ -1093,32 +1093,28 @@ __global__ __launch_bounds__(S2_NT, 4) void k_lms2(const LmsJob *__restrict__ jo
 // Per sample (3 barriers): products w[i]*hist[i] -> LDS (15 segments of 128, stride 130: bank-conflict-free
 // MFMA operand reads) | candidate pass (SpecSum: wave 15 -- no taps -- and waves 0..2) | wave 15 walks and publishes the sum the
 // walk predicts | update (nlms.h:114-129) with it by the tap waves while wave 15 verifies; redone from the kept weights in the
-// rare case that the prediction was not the exact sum (the loop below, L1_EARLY). The 512-thread build of tools/ has no spare
-// wave and keeps round 1's order: candidate pass | walk + verification | update. Predictions are buffered in LDS and written
-// out once per 256 samples.
+// rare case that the prediction was not the exact sum. (The 512-thread variant of round 2 -- no spare wave, round 1's order
+// candidate pass | walk + verification | update -- is in the history of this file.) Predictions are buffered in LDS and
+// written out once per 256 samples.
 // ------------------------------------------------------------------------------------------
-#ifndef L1_NT
 #define L1_NT 1024
-#endif
-#ifndef L1_EARLY
-#define L1_EARLY (L1_NT == 1024)
-#endif
 #define L1_R (2048 / L1_NT)
 #define L1_CH 256
-#define L1_RLO 2048
-#define L1_RLX 1024
+#define L1_HO (1281 + L1_CH)  // own channel's stage inputs:   ho[k] = x_own(tb - 1281 + k), tb = start of the current block of L1_CH samples
+#define L1_HX (641 + L1_CH)   // other channel's stage inputs: hx[k] = x_other(tb - 641 + k)
 
 __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs, const uint16_t *__restrict__ gtab, int bits, int ct0, int clen) {
-  constexpr int S = 1280, T = 1920, NT = L1_NT, R = L1_R, CH = L1_CH, MO = L1_RLO - 1, MX = L1_RLX - 1;
+  constexpr int S = 1280, T = 1920, NT = L1_NT, R = L1_R, CH = L1_CH;
   constexpr int SEG = L1_SEG, SEGP = L1_SEGP, NSEG = T / SEG;  // 15 segments of 128 products
   __shared__ double prods[16 * SEGP];  // (one buffer also with early prediction: the verifier works from registers)
-#if L1_EARLY
   __shared__ double sOut[32], vexact;
   __shared__ int specf, vok;
-#endif
   __shared__ double sA[16];  // approximate segment sums (the guess of spec_exact_sum)
-  __shared__ double ringo[L1_RLO];  // own channel's stage inputs   (taps 0..1279: lags 1..1280)
-  __shared__ double ringx[L1_RLX];  // other channel's stage inputs (taps 1280..1919)
+  // The history is not a ring (as in k_lms2): at a block edge the last 1281 / 641 values move down and the next block is loaded, a
+  // tap's value is at a per-thread base address that advances by 8 bytes per sample -- no index arithmetic per tap. (One value
+  // more than the filter is long: the redo of sample t - 1's update at a block edge reads one sample further back.)
+  __shared__ double ho[L1_HO];  // taps 0..1279: lags 1..1280
+  __shared__ double hx[L1_HX];  // taps 1280..1919
   __shared__ double pbuf[CH];
   __shared__ int sJ[16][16];
   __shared__ double sX1;
@@ -1147,39 +1143,30 @@ __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs
 #endif
   bits &= 0xff;
   for (int i = tid; i < (2 << bits); i += NT) tab[i] = gtab[i];
-  for (int i = tid; i < L1_RLO; i += NT) ringo[i] = 0.;
-  for (int i = tid; i < L1_RLX; i += NT) ringx[i] = 0.;
   for (int i = tid; i < 16 * SEGP; i += NT) prods[i] = 0.;  // chain 15 of the MFMA passes is idle: keep its operands finite
-  __syncthreads();
+  // history before the chunk comes straight from the stage's input arrays
+  for (int k = tid; k < L1_HO - CH; k += NT) { const int tau = t0 - (L1_HO - CH) + k; ho[k] = tau >= 0 ? xo_in[tau] : 0.; }
+  for (int k = tid; k < L1_HX - CH; k += NT) { const int tau = t0 - (L1_HX - CH) + k; hx[k] = tau >= 0 ? xx_in[tau] : 0.; }
 
-  double w[R], eg[R], mu[R];
-  uint32_t hb[R];  // LDS byte address of the tap's history ring (a generic pointer here made every history read a flat load)
-  int hoff[R], hmask[R], pa[R];
-  bool valid[R];
-  // carried state: same layout as k_lms<1280,640,...> (w at [tap], eg at [4096 + tap], tap = channel*1920 + i),
+  double w[R], eg[R];
+  // carried state: same layout as k_lms2 (w at [tap], eg at [4096 + tap], tap = channel*1920 + i),
   // so the two kernels may alternate between the chunks of one chain
   double *st = job.state ? job.state + c * T : nullptr;
-  // Half-wave `seg` (32 threads) owns the 128 taps of segment `seg`, lane l the taps l, 32+l, 64+l, 96+l of it:
-  // consecutive lanes read consecutive history values, and a segment's approximate sum is a half-wave reduction.
-  constexpr int HW = NT / 16;  // threads per segment: a half-wave (NT = 512) or a wave (NT = 1024)
-  static_assert(HW * R == SEG, "slots");
+  // Wave `seg` owns the 128 taps of segment `seg`, lane l the taps l and 64 + l of it: consecutive lanes read consecutive
+  // history values, and a segment's approximate sum is a wave reduction. Wave 15 owns no taps.
+  constexpr int HW = NT / 16;
+  static_assert(HW * R == SEG && R == 2, "slots");
   const int seg = tid / HW, hl = tid % HW;
-  int tap[R];
+  const bool valid = seg < NSEG, own = seg < S / SEG;
+  const int i0 = SEG * (valid ? seg : NSEG - 1) + hl;  // tap of slot 0; slot 1: i0 + 64  (wave 15 addresses what wave 14 addresses)
+  // history value of slot r at time t: own x_own(t - 1 - i) = ho[tl + 1280 - i]; other (j = i - 1280) x_other(t - lagx - j) = hx[tl + 641 - lagx - j]
+  const uint32_t a1 = own ? (uint32_t)(uintptr_t)&ho[0] + 8u * (uint32_t)(1280 - i0 - 64) : (uint32_t)(uintptr_t)&hx[0] + 8u * (uint32_t)(641 - lagx - (i0 - S) - 64);
+  const double mu = own ? job.mu1 : job.mu2;
+  const int pa = seg * SEGP + hl;  // product slot of slot 0; slot 1: + 64
 #pragma unroll
   for (int r = 0; r < R; r++) {
-    const int i = SEG * seg + HW * r + hl;
-    tap[r] = i;
-    valid[r] = seg < NSEG;
-    if (i < S) { hb[r] = (uint32_t)(uintptr_t)ringo; hmask[r] = MO; hoff[r] = (-(1 + i)) & MO; mu[r] = job.mu1; }
-    else { hb[r] = (uint32_t)(uintptr_t)ringx; hmask[r] = MX; hoff[r] = (-(lagx + (i - S))) & MX; mu[r] = job.mu2; }
-    pa[r] = seg * SEGP + HW * r + hl;
-    if (!valid[r]) { hb[r] = (uint32_t)(uintptr_t)ringo; hmask[r] = MO; hoff[r] = 0; pa[r] = 0; }
     w[r] = 0.; eg[r] = 0.;
-    if (t0 > 0 && st && valid[r]) { w[r] = st[i]; eg[r] = st[4096 + i]; }
-  }
-  if (t0 > 0) {  // history before the chunk comes straight from the stage's input arrays
-    for (int k = tid; k < L1_RLO - CH; k += NT) { const int tau = t0 - (L1_RLO - CH) + k; ringo[tau & MO] = tau >= 0 ? xo_in[tau] : 0.; }
-    for (int k = tid; k < L1_RLX - CH; k += NT) { const int tau = t0 - (L1_RLX - CH) + k; ringx[tau & MX] = tau >= 0 ? xx_in[tau] : 0.; }
+    if (t0 > 0 && st && valid) { w[r] = st[i0 + 64 * r]; eg[r] = st[4096 + i0 + 64 * r]; }
   }
   const int lane = tid & 63, wave = tid >> 6;
   long long rounds = 0;
@@ -1193,40 +1180,39 @@ __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs
 #else
 #define L1_TICK(i)
 #endif
+  auto lds_f64 = [](uint32_t addr) { return *(const __attribute__((address_space(3))) double *)(uintptr_t)addr; };
 
-  auto flush = [&](int tb, int te) {  // p and val[k+1] = x - p (CalcError, profile.cpp:141-148) for times [tb, te)
+  auto flush = [&](int tb, int te, int tcur) {  // p and val[k+1] = x - p (CalcError, profile.cpp:141-148) for times [tb, te); tcur: start of the block the history is based on
     for (int k = tid; k < CH; k += NT) {
       const int tau = tb + k;
       if (tau < te) {
         const double pv = pbuf[k];
         pout[tau] = pv;
-        if (xnout) xnout[tau] = ringo[tau & MO] - pv;
+        if (xnout) xnout[tau] = ho[tau - tcur + 1281] - pv;
       }
     }
   };
 
-#if L1_EARLY
   // ---- Early prediction. Wave 15 owns no taps: it is candidate group 0, the walker and the verifier (waves 0..2 are the other
   // candidate groups). When the walk ends on a candidate of the last boundary, the sum it predicts (sOut) is published at once
   // and the tap waves update -- and multiply for the next sample -- with it while wave 15 runs the verification pass(es). The
   // weights of before are kept for one sample; when the exact sum differs from the prediction (the walk was a guess: a few
   // per cent of the samples) the update and the products are done again. A sample's result is only ever the verified sum.
-  static_assert(NT == 1024, "the walker is the wave without taps");
   const int grp = wave == 15 ? 0 : (wave < 3 ? wave + 1 : -1);
   const bool walker = wave == 15;
   SpecSum<NSEG, SEGP> ss;
   double h[R], wS[R], egS[R];
   long long n_spec = 0, n_redo = 0;  // (L1_PROF statistics)
   int pend = 0;  // the update of sample t - 1 used a prediction: its verification is due behind the next barrier
-  auto products = [&](int t) {  // w[i]*hist[i] (nlms.h:111) -> prods, approximate segment sum -> sA
+  auto products = [&](int tl) {  // w[i]*hist[i] (nlms.h:111) -> prods, approximate segment sum -> sA; tl = t - block start
     double part = 0.;
+    const uint32_t a = a1 + 8u * (uint32_t)tl;
 #pragma unroll
-    for (int r = 0; r < R; r++)  // all history reads first: behind a product store the compiler would not move them
-      h[r] = *(const __attribute__((address_space(3))) double *)(uintptr_t)(hb[r] + 8u * (uint32_t)((t + hoff[r]) & hmask[r]));
+    for (int r = 0; r < R; r++) h[r] = lds_f64(a + 512u * (uint32_t)(1 - r));  // all history reads first: behind a product store the compiler would not move them
 #pragma unroll
     for (int r = 0; r < R; r++) {
       const double pr = w[r] * h[r];
-      if (UNCOND_UPDATE || valid[r]) prods[pa[r]] = pr;  // (every wave of this loop carries taps)
+      prods[pa + 64 * r] = pr;  // (every wave of this loop carries taps)
       part = r ? part + pr : pr;
     }
     part = row_prefix16(part);  // tree order: a guess only
@@ -1238,30 +1224,31 @@ __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs
     lo = __builtin_amdgcn_update_dpp(0, lo, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2 and 3
     hi = __builtin_amdgcn_update_dpp(0, hi, 0x143, 0xC, 0xF, false);
     part += __hiloint2double(hi, lo);
-    if (hl == HW - 1 && (UNCOND_UPDATE || valid[0])) sA[seg] = part;
+    if (hl == HW - 1) sA[seg] = part;
   };
-  auto update = [&](int t, double pred, const double (&hh)[R]) {  // nlms.h:114-129
-    const double err = ringo[t & MO] - pred;
+  auto update = [&](int tl, double pred, const double (&hh)[R]) {  // nlms.h:114-129; tl may be -1 (the redo of the last sample of the block before)
+    const double err = ho[1281 + tl] - pred;
 #pragma unroll
     for (int r = 0; r < R; r++) {
-      if ((UNCOND_UPDATE || valid[r]) && !(dbg & 2)) {
+      if (!(dbg & 2)) {
         const double grad = err * hh[r];
         eg[r] = 0.95 * eg[r] + (1.0 - 0.95) * (grad * grad);
-        w[r] += (mu[r] * grad * rsq_emul2(eg[r] + 0.001, tab, bits));
+        w[r] += (mu * grad * rsq_emul2(eg[r] + 0.001, tab, bits));
       }
     }
   };
-  auto settle = [&](int t, bool again) {  // behind a barrier: was the prediction used for sample t - 1 the exact sum?
-    if (pend && !vok) {  // no (uniform): update t - 1 again from the kept weights, with the exact sum
+  auto settle = [&](int tl, bool again) {  // behind a barrier: was the prediction used for the sample before (tl - 1) the exact sum?
+    if (pend && !vok) {  // no (uniform): update it again from the kept weights, with the exact sum
       n_redo++;
       double hold[R];
+      const uint32_t a = a1 + 8u * (uint32_t)(tl - 1);
 #pragma unroll
       for (int r = 0; r < R; r++) {
-        hold[r] = *(const __attribute__((address_space(3))) double *)(uintptr_t)(hb[r] + 8u * (uint32_t)((t - 1 + hoff[r]) & hmask[r]));
+        hold[r] = lds_f64(a + 512u * (uint32_t)(1 - r));
         w[r] = wS[r]; eg[r] = egS[r];
       }
-      update(t - 1, vexact, hold);
-      if (again) { products(t); __syncthreads(); }
+      update(tl - 1, vexact, hold);
+      if (again) { products(tl); __syncthreads(); }
     }
     pend = 0;
   };
@@ -1271,7 +1258,10 @@ __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs
   if (walker) {
     Op32 ops;
     for (int t = t0; t < tend; t++) {
-      if ((t & (CH - 1)) == 0) __syncthreads();  // (refill)
+      if (((t - t0) & (CH - 1)) == 0) {  // (block edge: the history moves, the next block is loaded)
+        if (t > t0) __syncthreads();
+        __syncthreads();
+      }
       L1_TICK(0)
       __syncthreads();
       if (pend && !vok) { n_redo++; __syncthreads(); }
@@ -1287,14 +1277,14 @@ __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs
         if (lane == 0) { predv = pv; specf = 1; }
       } else {  // the walk left the candidates at the last boundary: nothing to predict with
         const double ex = ss.template verify<true>(dbg, rounds, lane, hist, &ops);
-        if (lane == 0) { predv = ex; specf = 0; pbuf[t & (CH - 1)] = ex; }
+        if (lane == 0) { predv = ex; specf = 0; pbuf[(t - t0) & (CH - 1)] = ex; }
       }
       L1_TICK(1)
       __syncthreads();
       L1_TICK(2)
       if (sf) {
         const double ex = ss.template verify<true>(dbg, rounds, lane, hist, &ops);
-        if (lane == 0) { vok = __double_as_longlong(ex) == __double_as_longlong(pv); vexact = ex; pbuf[t & (CH - 1)] = ex; }
+        if (lane == 0) { vok = __double_as_longlong(ex) == __double_as_longlong(pv); vexact = ex; pbuf[(t - t0) & (CH - 1)] = ex; }
       }
       pend = sf;
       n_spec += sf;
@@ -1303,19 +1293,32 @@ __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs
     __syncthreads();
   } else {
     for (int t = t0; t < tend; t++) {
-      if ((t & (CH - 1)) == 0) {
+      const int tl = (t - t0) & (CH - 1);
+      if (tl == 0) {
+        if (t > t0) {  // the last L1_HO - CH / L1_HX - CH values move to the front (by the NTAP = 960 threads of this loop)
+          constexpr int NTAP = NT - 64;
+          static_assert(2 * NTAP >= L1_HO - CH && NTAP >= L1_HX - CH, "move");
+          double mo[2], mx;
+#pragma unroll
+          for (int u = 0; u < 2; u++) { const int k = tid + NTAP * u; mo[u] = k < L1_HO - CH ? ho[k + CH] : 0.; }
+          mx = tid < L1_HX - CH ? hx[tid + CH] : 0.;
+          __syncthreads();
+#pragma unroll
+          for (int u = 0; u < 2; u++) { const int k = tid + NTAP * u; if (k < L1_HO - CH) ho[k] = mo[u]; }
+          if (tid < L1_HX - CH) hx[tid] = mx;
+        }
         for (int k = tid; k < CH; k += NT) {
           const int tau = t + k;
-          ringo[tau & MO] = (tau < tend) ? xo_in[tau] : 0.;
-          ringx[tau & MX] = (tau < tend) ? xx_in[tau] : 0.;
+          ho[L1_HO - CH + k] = (tau < tend) ? xo_in[tau] : 0.;
+          hx[L1_HX - CH + k] = (tau < tend) ? xx_in[tau] : 0.;
         }
         __syncthreads();
       }
-      products(t);
+      products(tl);
       L1_TICK(0)
       __syncthreads();
-      settle(t, true);
-      if ((t & (CH - 1)) == 0 && t > t0) flush(t - CH, t);  // (behind the barrier: the last prediction of the block is the verifier's)
+      settle(tl, true);
+      if (tl == 0 && t > t0) flush(t - CH, t, t);  // (behind the barrier: the last prediction of the block is the verifier's)
       if (grp > 0) ss.template candidates<false, true>((uint32_t)(uintptr_t)&prods[0], sJ, &sX1, sA, sOut, grp, false, lane);
       __syncthreads();
       L1_TICK(1)
@@ -1324,89 +1327,22 @@ __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs
       const int sf = specf;
 #pragma unroll
       for (int r = 0; r < R; r++) { wS[r] = w[r]; egS[r] = eg[r]; }
-      update(t, predv, h);
+      update(tl, predv, h);
       pend = sf;
       L1_TICK(3)
     }
     __syncthreads();
-    settle(tend, false);
+    settle(((tend - 1 - t0) & (CH - 1)) + 1, false);
   }
-#else
-  for (int t = t0; t < tend; t++) {
-    if ((t & (CH - 1)) == 0) {
-      if (t > t0) flush(t - CH, t);
-      for (int k = tid; k < CH; k += NT) {
-        const int tau = t + k;
-        ringo[tau & MO] = (tau < tend) ? xo_in[tau] : 0.;
-        ringx[tau & MX] = (tau < tend) ? xx_in[tau] : 0.;
-      }
-      __syncthreads();
-    }
-    // ---- products w[i]*hist[i] (nlms.h:111). (Fetching the history values of sample t+1 during the update of t -- one LDS
-    // round trip less in front of the products -- measured 0.6 % slower.)
-    double h[R], part = 0.;
-#pragma unroll
-    for (int r = 0; r < R; r++)  // all history reads first: behind a product store the compiler would not move them
-      h[r] = *(const __attribute__((address_space(3))) double *)(uintptr_t)(hb[r] + 8u * (uint32_t)((t + hoff[r]) & hmask[r]));
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-      const double pr = w[r] * h[r];
-      if (valid[r]) prods[pa[r]] = pr;
-      part = r ? part + pr : pr;
-    }
-    // approximate segment sum (tree order: a guess only): 16-lane rows by DPP, then row 0 -> 1 and row 2 -> 3 (and rows 0..1 ->
-    // 2..3 when a whole wave owns the segment). Tried instead: the whole reduction as two v_mfma_f64_4x4x4 (B == 1) + two row
-    // rotations, 12 vector instructions instead of 36 -- 1 % slower: the wave that reaches the barrier last runs this alone on
-    // its SIMD, bound by the latency of the dependent chain, not by vector issue.
-    {
-      part = row_prefix16(part);
-      int lo = __double2loint(part), hi = __double2hiint(part);
-      lo = __builtin_amdgcn_update_dpp(0, lo, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1 and 3
-      hi = __builtin_amdgcn_update_dpp(0, hi, 0x142, 0xA, 0xF, false);
-      part += __hiloint2double(hi, lo);
-      if (HW == 64) {
-        lo = __double2loint(part); hi = __double2hiint(part);
-        lo = __builtin_amdgcn_update_dpp(0, lo, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2 and 3
-        hi = __builtin_amdgcn_update_dpp(0, hi, 0x143, 0xC, 0xF, false);
-        part += __hiloint2double(hi, lo);
-      }
-    }
-    if (hl == HW - 1 && valid[0]) sA[seg] = part;
-    L1_TICK(0)
-    __syncthreads();
-    // ---- pred = 0.; for i: pred += w[i]*hist[i]  -- strict order (spec_exact_sum: waves 0..3 sum candidates, wave 0 verifies)
-    const double res = spec_exact_sum<NSEG, SEG / 4, SEGP>((uint32_t)(uintptr_t)&prods[0], sJ, &sX1, sA, wave < 4 ? wave : -1, wave == 0, dbg, rounds, lane, hist);
-    if (wave == 0 && lane == SPEC_RESULT_LANE(NSEG)) {
-      predv = res;
-      pbuf[t & (CH - 1)] = res;
-    }
-    L1_TICK(1)
-    __syncthreads();
-    L1_TICK(2)
-    // ---- Update (nlms.h:114-129)
-    const double err = ringo[t & MO] - predv;
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-      if (valid[r] && !(dbg & 2)) {
-        const double grad = err * h[r];
-        eg[r] = 0.95 * eg[r] + (1.0 - 0.95) * (grad * grad);
-        w[r] += (mu[r] * grad * rsq_emul2(eg[r] + 0.001, tab, bits));
-      }
-    }
-    L1_TICK(3)
-  }
-#endif
-  if (tend > t0) flush((tend - 1) & ~(CH - 1), tend);
+  if (tend > t0) { const int tb = t0 + ((tend - 1 - t0) & ~(CH - 1)); flush(tb, tend, tb); }
 #ifdef L1_PROF
   __syncthreads();
   if (lane == 0 && tend - t0 >= 128) { for (int i = 0; i < 4; i++) pout[t0 + 4 * wave + i] = (double)pf[i]; }
-#if L1_EARLY
   if (tid == 960 && tend - t0 >= 128) { pout[t0 + 64] = (double)n_spec; pout[t0 + 65] = (double)n_redo; pout[t0 + 67] = (double)rounds; }
-#endif
 #endif
   if (dbg & 128) {  // DEBUG: number of P2 passes
     __syncthreads();
-    if (tid == (L1_EARLY ? 960 : 0)) pout[t0] = (double)rounds;
+    if (tid == 960) pout[t0] = (double)rounds;
   }
 #ifdef SACOPT_ABLATE
   if (dbg & 2048) {  // DEBUG: histogram of the largest distance (in ulps) between guess and exact value over the boundaries of a sample
@@ -1414,10 +1350,9 @@ __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs
     if (tid < 9) pout[t0 + tid] = (double)hist[tid];
   }
 #endif
-  if (st) {
+  if (st && valid) {
 #pragma unroll
-    for (int r = 0; r < R; r++)
-      if (valid[r]) { st[tap[r]] = w[r]; st[4096 + tap[r]] = eg[r]; }
+    for (int r = 0; r < R; r++) { st[i0 + 64 * r] = w[r]; st[4096 + i0 + 64 * r] = eg[r]; }
   }
 }
 
