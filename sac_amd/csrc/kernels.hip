@@ -587,6 +587,9 @@ static_assert(H_SPLIT == 192 || H_SPLIT == 224, "chains exist for 192 + 192 and 
 #ifndef LMS_HALVES_WAVES
 #define LMS_HALVES_WAVES 2  // candidate waves of the (256,128) stage's second half: 32 candidates per channel each
 #endif
+#ifndef LMS_TABG
+#define LMS_TABG 1  // 75-frame encode call, same run: 1276 -> 1251 ms; 2 (also the (256,128) stage: 768 look-ups per sample through the L1) 1284 ms
+#endif
 template <int S, int D, int NT, int R, int RL, bool SPEC, int CHP = LMS_CHUNK>
 __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, const uint16_t *__restrict__ gtab,
                                             int bits, int ct0, int clen) {
@@ -609,7 +612,12 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
   __shared__ int sJ[2][SPEC ? 16 : 1][16];
   __shared__ double sX1[2];
   __shared__ double sA[2][16];  // SPEC: approximate segment sums (the guess of spec_exact_sum)
-  __shared__ __attribute__((aligned(256))) uint16_t tab[RSQ_LDS_MAX];  // (most aligned = first in the LDS layout: its reads then take the base as an immediate offset)
+  // TABG: the single-wave stages (32,16) and (8,4) read the rsqrt table from global memory (16 KB: it stays in the CU's vector L1)
+  // instead of keeping a copy of their own in LDS -- 7 KB of LDS per workgroup instead of 23, so that they fit beside TWO lead
+  // workgroups (2 x 76.5 KB of the CU's 160)
+  constexpr bool TABG = (LMS_TABG >= 1 && NT == 64) || (LMS_TABG >= 2 && NT == 256);
+  __shared__ __attribute__((aligned(256))) uint16_t tab_l[TABG ? 1 : RSQ_LDS_MAX];  // (most aligned = first in the LDS layout: its reads then take the base as an immediate offset)
+  const uint16_t *const tab = TABG ? gtab : tab_l;
   // HALVES (the (256,128) stage): the 384-term chain of a channel is cut in two. Wave 0 sums the first half exactly from
   // +0 while waves 1 and 2 sum the second half from 2 x 32 candidate inputs per channel around a guess of the first half's sum
   // (rows of the MFMA = channel x 8 candidate groups, its 4 output columns keep their own C: 64 accumulators = 2 x 32
@@ -629,7 +637,7 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
   constexpr int dbg = 0;      // the product library has no switch that changes a result
 #endif
   bits &= 0xff;
-  for (int i = tid; i < (2 << bits); i += NT) tab[i] = gtab[i];
+  if (!TABG) for (int i = tid; i < (2 << bits); i += NT) tab_l[i] = gtab[i];
   for (int i = tid; i < 2 * RL; i += NT) (&ring[0][0])[i] = 0.;
   if (SPEC)
     for (int i = tid; i < 2 * TP; i += NT) (&prods[0][0])[i] = 0.;  // chain 15 of the MFMA passes is idle: keep its operands finite
@@ -911,10 +919,20 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
 #define S2_NT 512
 #define S2_CH 128
 #define S2_HL (1280 + S2_CH)
+#ifdef S2_OCC
+__device__ double s2occ[4 * 1024];
+#endif
 __global__ __launch_bounds__(S2_NT, 4) void k_lms2(const LmsJob *__restrict__ jobs, const uint16_t *__restrict__ gtab, int bits, int ct0, int clen) {
   constexpr int S = 1280, T = 1920, NT = S2_NT, CH = S2_CH, HL = S2_HL, R = 8;
   constexpr int SEG = L1_SEG, SEGP = L1_SEGP, NSEG = 15, TP = 16 * SEGP;
   __shared__ __attribute__((aligned(256))) uint16_t tab[RSQ_LDS_MAX];
+#ifdef S2_PAD  // (timing builds: so much more LDS that only one workgroup fits a CU)
+  __shared__ double s2pad[S2_PAD];
+  if (ct0 < 0) s2pad[threadIdx.x] = 1.;
+#endif
+#ifdef S2_OCC
+  const unsigned long long occ_t0 = wall_clock64();
+#endif
   __shared__ double prods[2][TP];
   __shared__ double hist[2][HL];
   __shared__ double pbuf[2][CH];
@@ -1081,7 +1099,18 @@ __global__ __launch_bounds__(S2_NT, 4) void k_lms2(const LmsJob *__restrict__ jo
       job.state[4096 + tp] = eg[r];
     }
   }
+#ifdef S2_OCC  // timing builds (tools/s2_occ.py): where and when this workgroup was resident
+  if (tid == 0 && blockIdx.x < 1024) {
+    s2occ[4 * blockIdx.x + 0] = (double)occ_t0;
+    s2occ[4 * blockIdx.x + 1] = (double)wall_clock64();
+    s2occ[4 * blockIdx.x + 2] = (double)__builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID
+    s2occ[4 * blockIdx.x + 3] = (double)__builtin_amdgcn_s_getreg((3 << 11) | 20);   // XCC_ID
+  }
+#endif
 }
+#ifdef S2_OCC
+extern "C" int sacopt_s2occ_read(double *host, int n) { return hipMemcpyFromSymbol(host, HIP_SYMBOL(s2occ), sizeof(double) * (size_t)n) != hipSuccess; }
+#endif
 
 // ------------------------------------------------------------------------------------------
 // LMSADA2(1280,640), one workgroup per (chain, CHANNEL). The two filters of a stereo pair only

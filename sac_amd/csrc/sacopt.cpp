@@ -26,11 +26,17 @@ extern "C" {
 int sacopt_lms_state_doubles(int S, int D);
 int sacopt_launch_lms(int S, int D, const LmsJob *jobs, int njobs, const uint16_t *tab, int bits, hipStream_t st, int limit, int ct0, int clen);
 int sacopt_lms_variant(int S, int D, int njobs, int bits, int limit);
-// (1280,640) stage: k_lms1c gives a chain two CUs (4.85k cycles per sample against 7.74k for both channels on one CU): taken
-// for up to 20 chains per launch. Beyond that a call is throughput-bound and the two-channel kernel is cheaper per CU. (A window
-// evaluation with up to 96 chains on k_lms1c changed nothing for encode calls of 2..15 frames: the full-frame pass bounds them.)
-#define L1C_FRAMES 20
+// (1280,640) stage: k_lms1c gives a chain two CUs (4.85k cycles per sample against ~8.6k for both channels on one CU). Full-frame
+// pass: taken for up to 48 frames per call -- measured on the encode call, same run, k_lms1c against k_lms2: 24 frames 592 / 665 ms,
+// 30: 676 / 705, 40: 805 / 840, 50: 966 / 972, 60: 1105 / 1076, 75: 1334 / 1284 (beyond ~50 frames the pass shares the chip with the
+// optimizer's rounds and the call is throughput-bound: the two-channel kernel is cheaper per CU). Optimizer windows: up to 20 chains
+// per launch (up to 96 chains on k_lms1c changed nothing for encode calls of 2..15 frames: the full-frame pass bounds them).
+#ifndef L1C_FRAMES
+#define L1C_FRAMES 48
+#endif
+#ifndef L1C_WINDOW
 #define L1C_WINDOW 20
+#endif
 int sacopt_launch_lpc3(const LpcJob *jobs, int njobs, int max_n, int ols_n, hipStream_t st);
 int sacopt_launch_lpc2(const LpcJob *jobs, int njobs, int max_n, hipStream_t st);
 int sacopt_launch_mix(int ns, const MixJob *jobs, int njobs, hipStream_t st, int ct0, int clen);
@@ -346,6 +352,9 @@ extern "C" int sacopt_create(int device, const float *rsqrt_tab, int rsqrt_bits,
         // has finished (75 frames: 12 % of the chip from the optimizer's third round on)
         if (masked) {
           bool ok = true;
+          // (Measured and not adopted: the optimizer's follower streams on 1 / 2 / 3 XCDs of their own, its lead stream on the others, so
+          // that two lead workgroups share every CU there -- 75 frames 2050 / 1480 / 1445 against 1280 ms: the lead launches do get
+          // 1.46x as much out of a CU, but the followers need more than a quarter of the chip.)
           for (int i = 0; i < 5 && ok; i++) ok = hipExtStreamCreateWithCUMask(&c->big[i], words, mall.data()) == hipSuccess;
           if (!ok) {
             (void)hipGetLastError();
