@@ -1404,6 +1404,9 @@ __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs
 //   ch0: Predict(v1(t-1)) ; ch1: Predict(v0(t))            (profile.cpp:128, :150-158)
 // ------------------------------------------------------------------------------------------
 #define LPC_N 24
+#ifndef CHOL_PK
+#define CHOL_PK 1  // k_chol: two snapshots per wave where 2 x (N + 1) rows fit (A/B switch)
+#endif
 #define LPC_S 16
 #define LPC_TRI (LPC_N * (LPC_N + 1) / 2) /* 300 */
 #define LPC_SNAP (LPC_TRI + LPC_N)        /* 324: packed lower triangle + b */
@@ -1481,29 +1484,45 @@ __global__ __launch_bounds__(LPC_COV_NT(N)) void k_cov(const LpcJob *__restrict_
 // Cholesky::Factor + Solve for one snapshot (cholesky.cpp:16-77). Lane r owns matrix row r;
 // lane N carries CalcY (:37-46) as an extra row. Each scalar's inner sum runs in the
 // reference's k order. FAST: full-order Solve(b,x) only, regp = 0; else all orders, regp = 500.
-template <bool FAST, int N = LPC_N>
-__device__ __forceinline__ bool chol_wave(const double *snap, double *solo, int lane) {  // true = "matrix indefinit", solo untouched
+// PK (N + 1 <= 32): TWO snapshots per wave, one per 32-lane half (snap / solo are then per-half pointers, `live` says whether
+// the half has a snapshot at all) -- the same instructions serve both, a broadcast is a ds_bpermute within the half instead of
+// a v_readlane. 25 of 64 lanes carried a row before, 50 do now: per snapshot half the instructions (k_chol is issue-bound:
+// profiles/r03b_pmc_75frames.json, 12 % of the vector-ALU cycles of a 75-frame call).
+template <bool FAST, int N = LPC_N, bool PK = false>
+__device__ __forceinline__ bool chol_wave(const double *snap, double *solo, int lane_, bool live = true) {  // true = "matrix indefinit", solo untouched
   constexpr int TRI = LPC_TRI_(N);
   constexpr double REGP = FAST ? 0. : 500.;
   static_assert(N < 64, "one lane per matrix row + one for CalcY");
+  static_assert(!PK || N < 32, "a half-wave per snapshot");
+  const int lane = PK ? (lane_ & 31) : lane_;
+  const int half4 = (lane_ & 32) << 2;  // byte address of the half's lane 0 for ds_bpermute
+  auto bc = [&](double v, int src) -> double {
+    if constexpr (PK) {
+      const int lo = __builtin_amdgcn_ds_bpermute(half4 + 4 * src, __double2loint(v));
+      const int hi = __builtin_amdgcn_ds_bpermute(half4 + 4 * src, __double2hiint(v));
+      return __hiloint2double(hi, lo);
+    } else return bcast(v, src);
+  };
   double m[N];
   const int row = lane <= N ? lane : 0;
 #pragma unroll
   for (int q = 0; q < N; q++) {
     double v = 0.;
-    if (row < N) { if (q <= row) v = snap[row * (row + 1) / 2 + q]; }
-    else v = snap[TRI + q];
+    if (live) {
+      if (row < N) { if (q <= row) v = snap[row * (row + 1) / 2 + q]; }
+      else v = snap[TRI + q];
+    }
     if (q == lane) v += REGP;  // cholesky.cpp:20
     m[q] = v;
   }
-  bool fail = false;
+  bool fail = !live;
 #pragma unroll
   for (int j = 0; j < N; j++) {
     if (!fail) {
       double sum = m[j];
 #pragma unroll
-      for (int q = 0; q < j; q++) sum -= (m[q] * bcast(m[q], j));
-      const double dj = bcast(sum, j);
+      for (int q = 0; q < j; q++) sum -= (m[q] * bc(m[q], j));
+      const double dj = bc(sum, j);
       if (dj > 0.) {
         const double diag = sqrt(dj);
         m[j] = (lane == j) ? diag : sum / diag;
@@ -1517,13 +1536,13 @@ __device__ __forceinline__ bool chol_wave(const double *snap, double *solo, int 
   if constexpr (!FAST) {  // Solve(b) for every leading order (cholesky.cpp:63-77): lane o = order o
 #pragma unroll
     for (int i = N - 1; i >= 0; i--) {
-      double sum = bcast(m[i], N);
+      double sum = bc(m[i], N);
 #pragma unroll
       for (int j = i + 1; j < N; j++) {
-        const double mji = bcast(m[i], j);
+        const double mji = bc(m[i], j);
         if (j <= lane) sum -= (mji * sol[j]);
       }
-      const double d = bcast(m[i], i);
+      const double d = bc(m[i], i);
       if (i <= lane) sol[i] = sum / d;
     }
     if (lane < N) {
@@ -1534,10 +1553,10 @@ __device__ __forceinline__ bool chol_wave(const double *snap, double *solo, int 
   } else {  // Solve(b, x) (cholesky.cpp:48-60), uniform across lanes
 #pragma unroll
     for (int i = N - 1; i >= 0; i--) {
-      double sum = bcast(m[i], N);
+      double sum = bc(m[i], N);
 #pragma unroll
-      for (int j = i + 1; j < N; j++) sum -= (bcast(m[i], j) * sol[j]);
-      sol[i] = sum / bcast(m[i], i);
+      for (int j = i + 1; j < N; j++) sum -= (bc(m[i], j) * sol[j]);
+      sol[i] = sum / bc(m[i], i);
     }
     if (lane == 0) {
 #pragma unroll
@@ -1548,14 +1567,18 @@ __device__ __forceinline__ bool chol_wave(const double *snap, double *solo, int 
 }
 template <bool FAST, int N>
 __global__ __launch_bounds__(64) void k_chol(const LpcJob *__restrict__ jobs) {
+  constexpr bool PK = CHOL_PK && N < 32;  // two snapshots per wave
   const LpcJob &job = jobs[blockIdx.y >> 1];
-  const int ch = blockIdx.y & 1, k = job.t0 / (FAST ? 32 : 8) + blockIdx.x, lane = threadIdx.x;
-  if (k >= job.nsnap) return;
+  const int lane = threadIdx.x;
+  const int ch = blockIdx.y & 1, k = job.t0 / (FAST ? 32 : 8) + (PK ? 2 * blockIdx.x + (lane >> 5) : blockIdx.x);
+  const bool live = k < job.nsnap;
+  if (!PK && !live) return;
+  if (PK && job.t0 / (FAST ? 32 : 8) + 2 * (int)blockIdx.x >= job.nsnap) return;  // (uniform: neither half has a snapshot)
   const double *snap = (ch ? job.snap[1] : job.snap[0]) + (size_t)k * LPC_SNAP_(N);
   double *solo = (ch ? job.sol[1] : job.sol[0]) + (size_t)k * (FAST ? N : LPC_TRI_(N));
   int32_t *failo = (ch ? job.fail[1] : job.fail[0]) + k;
-  const bool fail = chol_wave<FAST, N>(snap, solo, lane);
-  if (lane == 0) *failo = fail ? 1 : 0;
+  const bool fail = chol_wave<FAST, N, PK>(snap, solo, lane, live);
+  if ((PK ? (lane & 31) : lane) == 0 && live) *failo = fail ? 1 : 0;
 }
 
 // index of the snapshot whose solution is in force when predicting sample t (-1: none yet)
@@ -2203,7 +2226,7 @@ template <int N, int S>
 static int launch_lpc3_ns(const LpcJob *jobs, int njobs, int max_n, hipStream_t st) {
   const int max_snap = max_n / 8;
   hipLaunchKernelGGL((k_cov<8, N, S>), dim3(njobs, 2), dim3(LPC_COV_NT(N)), 0, st, jobs);
-  if (max_snap) hipLaunchKernelGGL((k_chol<false, N>), dim3(max_snap, 2 * njobs), dim3(64), 0, st, jobs);
+  if (max_snap) hipLaunchKernelGGL((k_chol<false, N>), dim3((CHOL_PK && N < 32) ? (max_snap + 1) / 2 : max_snap, 2 * njobs), dim3(64), 0, st, jobs);
   hipLaunchKernelGGL((k_ssum<N, S>), dim3((unsigned)(((long long)max_n * N + 255) / 256), 2 * njobs), dim3(256), 0, st, jobs);
   hipLaunchKernelGGL((k_serr<N>), dim3(njobs, 2), dim3(64), 0, st, jobs);
   hipLaunchKernelGGL((k_pm<N>), dim3((max_n + 255) / 256, 2 * njobs), dim3(256), 0, st, jobs);
@@ -2220,7 +2243,7 @@ extern "C" int sacopt_launch_lpc2(const LpcJob *jobs, int njobs, int max_n, hipS
   if (njobs <= 0 || max_n <= 0) return 0;
   const int max_snap = max_n / 32;
   hipLaunchKernelGGL((k_cov<32, LPC_N, LPC_S>), dim3(njobs, 2), dim3(LPC_COV_NT(LPC_N)), 0, st, jobs);
-  if (max_snap) hipLaunchKernelGGL((k_chol<true, LPC_N>), dim3(max_snap, 2 * njobs), dim3(64), 0, st, jobs);
+  if (max_snap) hipLaunchKernelGGL((k_chol<true, LPC_N>), dim3(CHOL_PK ? (max_snap + 1) / 2 : max_snap, 2 * njobs), dim3(64), 0, st, jobs);
   hipLaunchKernelGGL(k_pred2, dim3((max_n + 255) / 256, 2 * njobs), dim3(256), 0, st, jobs);
   return hipGetLastError() != hipSuccess;
 }

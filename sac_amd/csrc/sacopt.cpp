@@ -31,6 +31,9 @@ int sacopt_lms_variant(int S, int D, int njobs, int bits, int limit);
 // 30: 676 / 705, 40: 805 / 840, 50: 966 / 972, 60: 1105 / 1076, 75: 1334 / 1284 (beyond ~50 frames the pass shares the chip with the
 // optimizer's rounds and the call is throughput-bound: the two-channel kernel is cheaper per CU). Optimizer windows: up to 20 chains
 // per launch (up to 96 chains on k_lms1c changed nothing for encode calls of 2..15 frames: the full-frame pass bounds them).
+#ifndef ROUND_CHUNKS_BIG
+#define ROUND_CHUNKS_BIG 16  // chunks per optimizer window when a round's lead launch has more workgroups than the chip has CUs
+#endif
 #ifndef L1C_FRAMES
 #define L1C_FRAMES 48
 #endif
@@ -779,7 +782,7 @@ static int eval_chains(sacopt_ctx *c, const ProfDesc &pd, const std::vector<DevF
   // the round ends one follower-chunk after the lead stage's last chunk
   // (measured, one gpurun call: 8 / 16 / 24 chunks: 15 frames 448 / 433 / 432 ms, 75 frames 1670 / 1690 / 1735 ms; 3 chunks: 75 frames
   // 1660 ms but 30 frames 807 against 753 ms)
-  constexpr int ROUND_CHUNKS = 16;
+  const int ROUND_CHUNKS = (todo_s[lead].size() > 256) ? ROUND_CHUNKS_BIG : 16;
   const int chunk = (max_n >= 8 * LMS_CHUNK) ? ((max_n + ROUND_CHUNKS * LMS_CHUNK - 1) / (ROUND_CHUNKS * LMS_CHUNK)) * LMS_CHUNK : (max_n > 0 ? max_n : 1);
   const int nchunk = max_n > 0 ? (max_n + chunk - 1) / chunk : 1;
   const bool carry = nchunk > 1;

@@ -18,5 +18,10 @@ timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d gpurun_out/kt75 -o kt --
 echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --no-extras --frames 75 --steps 2 --warmup 1   (3 calls of 75 frames x 176400; summarised by tools/prof_summary.py)" > $O/${TAG}_kernel_stats_75frames.txt
 python3 tools/prof_summary.py gpurun_out/kt75/kt_results.db >> $O/${TAG}_kernel_stats_75frames.txt
 rm -rf gpurun_out/kt75
+timeout -s KILL 400 rocprofv3 --pmc FETCH_SIZE -d gpurun_out/p75f -o p -- python3 bench.py --no-extras --frames 75 --steps 1 --warmup 0 > /dev/null 2> $O/pmc75_f.log
+timeout -s KILL 400 rocprofv3 --pmc WRITE_SIZE -d gpurun_out/p75w -o p -- python3 bench.py --no-extras --frames 75 --steps 1 --warmup 0 > /dev/null 2> $O/pmc75_w.log
+timeout -s KILL 400 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_F64 SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT -d gpurun_out/p75s -o p -- python3 bench.py --no-extras --frames 75 --steps 1 --warmup 0 > /dev/null 2> $O/pmc75_s.log
+python3 tools/pmc75_summary.py $O/${TAG}_pmc_75frames.json gpurun_out/p75f/p_results.db gpurun_out/p75w/p_results.db gpurun_out/p75s/p_results.db > $O/pmc75_summary.txt
+rm -rf gpurun_out/p75f gpurun_out/p75w gpurun_out/p75s
 rm -rf gpurun_out/kt gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_sq
-head -12 $O/${TAG}_kernel_stats.txt | cut -c1-150; cat $O/pmc_summary.txt
+head -12 $O/${TAG}_kernel_stats.txt | cut -c1-150; cat $O/pmc_summary.txt; head -10 $O/${TAG}_kernel_stats_75frames.txt | cut -c1-150; cat $O/pmc75_summary.txt
