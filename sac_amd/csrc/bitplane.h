@@ -24,6 +24,12 @@
 #define BP_NC2 258   // bpn2[0], bpn2[1 + ctx1]: indices < 257
 #define BP_NW 42     // lmixref[8][3], lmixsig[8][2], finalmix[2]  (mixctx = state & 7: 8 of the 32 mixers are ever used)
 #define BP_DIVN 1024 // div_tbl entries reachable with the coder's counter limit (1000)
+#ifndef BP_PIPE
+#define BP_PIPE 1        // stage-pipeline form k_bppipe for passes of up to BP_PIPE_MAX buffers (A/B switch)
+#endif
+#ifndef BP_PIPE_MAX
+#define BP_PIPE_MAX 8192
+#endif
 #ifndef BP_WPC_MAX
 #define BP_WPC_MAX 2048  // ... and up to this many the wave-per-coder form (8 coders per workgroup: one workgroup per CU, 256 CUs)
 #endif
@@ -292,5 +298,256 @@ __global__ __launch_bounds__(WPC ? 64 * LPW : 64) void k_bpsize(const BpJob *__r
   if (live) {
     for (int i = 0; i < 5; i++) shift_low();  // RangeCoderSH::Stop, range.cpp:60-63
     if (wr) sizes[b] = pos;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Stage-pipeline form (round 3). On the ENCODER side every context and every coded bit is a function of the residuals alone,
+// so the coder's adaptive parts only feed FORWARD: counters -> mixer -> SSE -> final mixer -> range coder; nothing a later
+// part computes is read by an earlier one. The one chain of ~450 dependent instructions per decision therefore splits into
+// five shorter ones that run side by side, one wave each, a block of 64 decisions apart:
+//   S0  contexts of 64 decisions at once (a lane per sample: msb values are highest-set-bit tests against the plane number)
+//   S1  the three bit counters of a decision (lanes 0..2), predictions to LDS
+//   S2  NMixLogistic of the decision's context: stretch, dot product, squash, weight update
+//   S3  SSENL of context (bpn << 5) + msb: one plane's maps in LDS, re-initialised per plane (a plane's contexts are its own)
+//   S4  final mixer + RangeCoderSH byte count
+// Iteration `it` of the workgroup loop: stage i works on block it - i, one workgroup barrier per iteration; the hand-over
+// buffers are rings of 8 blocks in LDS. The time per decision is the slowest stage's chain (~300 cycles) instead of the sum.
+// Two coders per workgroup share the 74 KB of tables (10 waves, one workgroup per CU: 512 coders in flight on the chip).
+// Same integer arithmetic, same order of updates per counter / weight / bin: sizes identical to k_bpsize.
+// branch-free forms of the rounding shifts and clamps (the values of the serial loops are wave-uniform: the compiler keeps them in
+// scalar registers and turned every `x < 0 ? .. : ..` into a scalar branch, ~25 cycles each, twenty per decision)
+__device__ __forceinline__ int bpp_idiv32(int val, int sh) { const int m = val >> 31; return ((((val ^ m) - m) + (1 << (sh - 1))) >> sh ^ m) - m; }
+__device__ __forceinline__ long long bpp_idiv64(long long val, int sh) { const long long m = val >> 63; return ((((val ^ m) - m) + (1ll << (sh - 1))) >> sh ^ m) - m; }
+__device__ __forceinline__ int bpp_clamp(int v, int lo, int hi) { return max(lo, min(v, hi)); }
+#ifndef BPP_ALLSTORE
+#define BPP_ALLSTORE 1  // stores of wave-uniform values by every lane (no exec-mask branch) instead of lane 0 only
+#endif
+#if BPP_ALLSTORE
+#define BPP_ONE
+#else
+#define BPP_ONE if (lane == 0)
+#endif
+#define BPP_B 64
+#define BPP_RING 8
+#define BPP_NCOD 2
+#define BPP_STAGES 5
+#define BPP_NT (BPP_NCOD * BPP_STAGES * 64)
+#define BPP_SSE (32 * 2 * 33)
+__global__ __launch_bounds__(BPP_NT) void k_bppipe(const BpJob *__restrict__ jobs, int nbuf, BpTables tb, int32_t *__restrict__ sizes) {
+  __shared__ int16_t fwd[BP_PSCALE];
+  __shared__ uint16_t inv[(1 << BP_DBITS) + 2];  // [0] = 0 and [4097] = PSCALE - 1: LogDomain::Inv beyond its table (domain.h:33-38)
+  __shared__ uint16_t divt[BP_DIVN];
+  __shared__ uint16_t sinit[BP_SSE_N + 1];
+  __shared__ uint32_t rec[BPP_NCOD][BPP_RING][BPP_B];
+  __shared__ uint16_t pcs[BPP_NCOD][BPP_RING][4][BPP_B];  // (row 3: where the lanes without a counter store)
+  __shared__ uint16_t pds[BPP_NCOD][BPP_RING][BPP_B], pss[BPP_NCOD][BPP_RING][BPP_B];
+  __shared__ uint16_t c1[BPP_NCOD][BP_NC1], c2[BPP_NCOD][BP_NC2];
+  __shared__ int wts[BPP_NCOD][48];  // lmixref[8][3], lmixsig[8][2 + one weight that stays 0 (its input is 0)]
+  __shared__ uint32_t ssel[BPP_NCOD][BPP_SSE];  // [(msb * 2 + lb) * 33 + q]: p1 | counter << 16
+  __shared__ int32_t tile[BPP_NCOD][BPP_B + 8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cod = wave / BPP_STAGES, stage = wave - cod * BPP_STAGES;
+  const int b = blockIdx.x * BPP_NCOD + cod;
+  const bool live = b < nbuf;
+  for (int i = tid; i < BP_PSCALE; i += BPP_NT) fwd[i] = tb.fwd[i];
+  for (int i = tid; i < (1 << BP_DBITS); i += BPP_NT) inv[i + 1] = tb.inv[i];
+  if (tid == 0) { inv[0] = 0; inv[(1 << BP_DBITS) + 1] = BP_PSCALE - 1; }
+  for (int i = tid; i < BP_DIVN; i += BPP_NT) divt[i] = (uint16_t)(BP_PSCALE / (i + 3));  // counter.h:38-50
+  if (tid <= BP_SSE_N) sinit[tid] = tb.sse_init[tid];
+  for (int i = tid; i < BPP_NCOD * BP_NC1; i += BPP_NT) (&c1[0][0])[i] = BP_PSCALE >> 1;
+  for (int i = tid; i < BPP_NCOD * BP_NC2; i += BPP_NT) (&c2[0][0])[i] = BP_PSCALE >> 1;
+  for (int i = tid; i < BPP_NCOD * 48; i += BPP_NT) (&wts[0][0])[i] = 0;  // NMixLogistic::Init(0)
+  const int n = live ? jobs[b].n : 0, mbp = live ? jobs[b].maxbpn : -1;
+  const int32_t *buf = live ? jobs[b].buf : nullptr;
+  const int nb = (n + BPP_B - 1) / BPP_B;
+  const int nblk = (n > 0 && mbp >= 0) ? (mbp + 1) * nb : 0;
+  int nblk_max = 0;  // (the loop holds workgroup barriers: its bound is the same in every wave)
+  for (int k = 0; k < BPP_NCOD; k++) {
+    const int bb = blockIdx.x * BPP_NCOD + k;
+    if (bb < nbuf) {
+      const int nn = jobs[bb].n, mm = jobs[bb].maxbpn;
+      const int q = (nn > 0 && mm >= 0) ? (mm + 1) * ((nn + BPP_B - 1) / BPP_B) : 0;
+      nblk_max = q > nblk_max ? q : nblk_max;
+    }
+  }
+  const int tscale = tb.tscale, xscale = tb.xscale;
+  const uint32_t xmagic = (uint32_t)((0x100000000ull + (uint32_t)xscale - 1) / (uint32_t)xscale);
+  auto divx = [&](int x) -> int { int q = (int)__umulhi((uint32_t)x, xmagic); q -= (q * xscale > x) ? 1 : 0; return q; };
+  auto dinv = [&](int x) -> int { return (int)inv[bpp_clamp(x, -(1 << (BP_DBITS - 1)) - 1, 1 << (BP_DBITS - 1)) + (1 << (BP_DBITS - 1)) + 1]; };
+  // S3 / S4 state (registers of the stage's wave)
+  uint32_t lbreg = 0;
+  int wf0 = 0, wf1 = 0;
+  uint32_t range = 0xFFFFFFFFu, ffnum = 0;
+  unsigned long long lowc = 0;
+  int pos = 0;
+  auto shift_low = [&]() {  // RangeCoderSH::ShiftLow (range.cpp:80-90), counting the bytes it would put
+    const uint32_t carry = (uint32_t)(lowc >> 32), low = (uint32_t)lowc;
+    if (low < 0xFF000000u || carry) { pos += 1 + (int)ffnum; ffnum = 0; }
+    else ffnum++;
+    lowc = (unsigned long long)(low << 8);
+  };
+  __syncthreads();
+#ifdef BPP_PROF  // busy cycles of every stage wave of workgroup 0 (timing builds)
+  long long busy = 0;
+#endif
+  for (int it = 0; it < nblk_max + BPP_STAGES - 1; it++) {
+    const int k = it - stage;
+#ifdef BPP_PROF
+    const long long tb0 = clock64();
+#endif
+    if (k >= 0 && k < nblk) {
+      const int pl = k / nb, bpn = mbp - pl, s0 = (k - pl * nb) * BPP_B, slot = k & (BPP_RING - 1);
+      const int jn = min(BPP_B, n - s0);  // decisions of this block
+      if (stage == 0) {  // ---- contexts (vle.cpp:17-28, 32-60, 71-92), a lane per sample
+        for (int i = lane; i < BPP_B + 8; i += 64) { const int idx = s0 - 4 + i; tile[cod][i] = (idx >= 0 && idx < n) ? buf[idx] : 0; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        int a[9];
+#pragma unroll
+        for (int q = 0; q < 9; q++) a[q] = tile[cod][lane + q];  // a[4] = abuf[s]
+        __builtin_amdgcn_wave_barrier();
+        const int s = s0 + lane;
+        auto hb = [](int x) -> int { return x ? 31 - __clz(x) : -1; };
+        // msb[] of a sample (vle.cpp:132: the plane of its first set bit, once that plane's decision has been coded; 0 before --
+        // and for good when that plane is 0): `before` its decision in this plane, and `after`
+        auto before = [&](int x) -> int { const int h = hb(x); return h > bpn ? h : 0; };
+        auto after = [&](int x) -> int { const int h = hb(x); return h >= bpn ? h : 0; };
+        const int mymsb = before(a[4]);
+        const bool sig = mymsb != 0;
+        const int bit = (a[4] >> bpn) & 1;
+        int state = 0;  // (state << 1) + !significant per coded decision of this plane (vle.cpp:128): the last three
+#pragma unroll
+        for (int q = 1; q <= 3; q++) if (s - q >= 0 && before(a[4 - q]) == 0) state |= 1 << (q - 1);
+        int idx1, idx2 = 0;
+        if (sig) {
+          const int tval = a[4] >> (bpn + 1), tval1 = tval << 1;
+          int lctx = 0;
+          if ((a[3] >> bpn) > tval1) lctx += 1;
+          if ((a[5] >> (bpn + 1)) > tval) lctx += 2;
+          if ((a[2] >> bpn) > tval1) lctx += 4;
+          if ((a[6] >> (bpn + 1)) > tval) lctx += 8;
+          idx1 = 1 + mymsb;
+          idx2 = 1 + 32 + lctx;
+        } else {
+          int ctx1 = 0;
+          if (after(a[3])) ctx1 += 1;
+          if (before(a[5])) ctx1 += 2;
+          if (after(a[2])) ctx1 += 4;
+          if (before(a[6])) ctx1 += 8;
+          if (after(a[1])) ctx1 += 16;
+          if (before(a[7])) ctx1 += 32;
+          if (after(a[0])) ctx1 += 64;
+          if (before(a[8])) ctx1 += 128;
+          idx1 = 1 + ctx1;
+        }
+        rec[cod][slot][lane] = (uint32_t)bit | ((uint32_t)sig << 1) | ((uint32_t)state << 2) | ((uint32_t)mymsb << 5) | ((uint32_t)idx1 << 10) |
+                               ((uint32_t)idx2 << 19) | ((s < n) ? 0x80000000u : 0u);
+      } else if (stage == 1) {  // ---- LinearCounter16 x 3 (counter.h:30-35, rate 350: vle.cpp:62-69, 94-101), lane = counter slot
+        // (stages 1-4: what a decision needs and no earlier decision changes is fetched for the whole block at once, a lane per
+        // decision; the serial loop takes decision j's values out of lane j)
+        const uint32_t rv = rec[cod][slot][lane];
+        for (int j = 0; j < jn; j++) {
+          const uint32_t r = __builtin_amdgcn_readlane(rv, j);
+          const int bit = r & 1, sig = (r >> 1) & 1, idx1 = (r >> 10) & 511, idx2 = (r >> 19) & 63;
+          // lane 0: bpn2[0]; lane 1: bpn1[1 + msb] / bpn2[1 + ctx1]; lane 2: bpn1[33 + lctx], or an unused counter when the
+          // decision has two inputs (its prediction is not read then); the other lanes: that unused counter
+          const int i1 = sig ? idx1 : 0, i2 = sig ? 0 : idx1;  // index into c1 (bpn1) / c2 (bpn2)
+          uint16_t *addr = lane == 0 ? &c2[cod][0] : (lane == 1 ? (sig ? &c1[cod][i1] : &c2[cod][i2]) : &c1[cod][(lane == 2 && sig) ? idx2 : 63]);
+          const int p = *addr;
+          const int err = (bit << BP_PBITS) - p;
+          *addr = (uint16_t)bpp_clamp(p + bpp_idiv32(__mul24(350, err), BP_PBITS), 1, BP_PSCALEm);
+          pcs[cod][slot][min(lane, 3)][j] = (uint16_t)p;
+        }
+      } else if (stage == 2) {  // ---- NMixLogistic (mixer.h:73-93, rate 800)
+        const uint32_t rv = rec[cod][slot][lane];
+        const int xv0 = fwd[pcs[cod][slot][0][lane] & BP_PSCALEm], xv1 = fwd[pcs[cod][slot][1][lane] & BP_PSCALEm],
+                  xv2 = ((rv >> 1) & 1) ? (int)fwd[pcs[cod][slot][2][lane] & BP_PSCALEm] : 0;
+        uint16_t pdv = 0;
+        for (int j = 0; j < jn; j++) {
+          const uint32_t r = __builtin_amdgcn_readlane(rv, j);
+          const int bit = r & 1, sig = (r >> 1) & 1, mixctx = (r >> 2) & 7;
+          const int x0 = __builtin_amdgcn_readlane(xv0, j), x1 = __builtin_amdgcn_readlane(xv1, j), x2 = __builtin_amdgcn_readlane(xv2, j);
+          int *w = &wts[cod][(mixctx + 8 * (1 - sig)) * 3];
+          const int w0 = w[0], w1 = w[1], w2 = w[2];
+          const long long sum = (long long)__mul24(w0, x0) + (long long)__mul24(w1, x1) + (long long)__mul24(w2, x2);
+          const int pd = bpp_clamp(dinv((int)bpp_idiv64(sum, BP_WBITS)), 1, BP_PSCALEm);
+          const int err = (bit << BP_PBITS) - pd;
+          const int n0 = bpp_clamp(w0 + bpp_idiv32(__mul24(bpp_idiv32(__mul24(x0, err), BP_DBITS), 800), BP_DBITS), -BP_WRANGE, BP_WRANGE - 1);
+          const int n1 = bpp_clamp(w1 + bpp_idiv32(__mul24(bpp_idiv32(__mul24(x1, err), BP_DBITS), 800), BP_DBITS), -BP_WRANGE, BP_WRANGE - 1);
+          const int n2 = bpp_clamp(w2 + bpp_idiv32(__mul24(bpp_idiv32(__mul24(x2, err), BP_DBITS), 800), BP_DBITS), -BP_WRANGE, BP_WRANGE - 1);
+          BPP_ONE { w[0] = n0; w[1] = n1; w[2] = n2; }
+          if (lane == j) pdv = (uint16_t)pd;
+        }
+        pds[cod][slot][lane] = pdv;
+      } else if (stage == 3) {  // ---- SSENL<32> (sse.h:94-124, limit 1000) of context (bpn << 5) + msb (vle.cpp:96-108)
+        if (s0 == 0) {  // a new plane: its maps start from the constructor's values
+          for (int e = lane; e < BPP_SSE; e += 64) ssel[cod][e] = sinit[e % 33];
+          lbreg = 0;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+        }
+        const uint32_t rv = rec[cod][slot][lane];
+        int qv;
+        {
+          int pq = (int)fwd[pds[cod][slot][lane] & BP_PSCALEm] + tscale;
+          pq = pq < 0 ? 0 : (pq > 2 * tscale ? 2 * tscale : pq);
+          const int q = divx(pq);
+          qv = q | ((pq - q * xscale) << 8);
+        }
+        uint16_t psv = 0;
+        for (int j = 0; j < jn; j++) {
+          const uint32_t r = __builtin_amdgcn_readlane(rv, j);
+          const int bit = r & 1, mymsb = (r >> 5) & 31;
+          const int qq = __builtin_amdgcn_readlane(qv, j), q = qq & 255, pmod = qq >> 8;
+          const int lb = (int)((lbreg >> mymsb) & 1u);
+          uint32_t *e0 = &ssel[cod][(mymsb * 2 + lb) * 33 + q];
+          const uint32_t v0 = e0[0], v1 = e0[1];
+          const int pl0 = (int)(v0 & 0xffffu), ph0 = (int)(v1 & 0xffffu);
+          const int ps = bpp_clamp(divx(__mul24(pl0, xscale - pmod) + __mul24(ph0, pmod)), 1, BP_PSCALEm);
+          auto lcl = [&](uint32_t v) -> uint32_t {  // LinearCounterLimit::update, counter.h:57-65
+            int p1 = (int)(v & 0xffffu);
+            const int cnt = min((int)(v >> 16) + 1, 1000);
+            const int dv = (int)divt[cnt];
+            const int nb1 = bit - 1;  // 0 / -1
+            const int d = __mul24(p1 + bit * (BP_PSCALE - 2 * p1), dv) >> BP_PBITS;  // bit ? (PSCALE - p1) * dv : p1 * dv
+            p1 = bpp_clamp(p1 + ((d ^ nb1) - nb1), 1, BP_PSCALEm);
+            return (uint32_t)p1 | ((uint32_t)cnt << 16);
+          };
+          const uint32_t u0 = lcl(v0), u1 = lcl(v1);
+          BPP_ONE { e0[0] = u0; e0[1] = u1; }
+          if (lane == j) psv = (uint16_t)ps;
+          lbreg = (lbreg & ~(1u << mymsb)) | ((uint32_t)bit << mymsb);
+        }
+        pss[cod][slot][lane] = psv;
+      } else {  // ---- finalmix[0].Predict({sse, p1}) (vle.cpp:100-102, rate 300) + RangeCoderSH::EncodeBitOne (range.cpp:65-70)
+        const uint32_t rv = rec[cod][slot][lane];
+        const int yv0 = fwd[pss[cod][slot][lane] & BP_PSCALEm], yv1 = fwd[pds[cod][slot][lane] & BP_PSCALEm];
+        for (int j = 0; j < jn; j++) {
+          const uint32_t r = __builtin_amdgcn_readlane(rv, j);
+          const int bit = r & 1;
+          const int y0 = __builtin_amdgcn_readlane(yv0, j), y1 = __builtin_amdgcn_readlane(yv1, j);
+          const long long fs = (long long)__mul24(wf0, y0) + (long long)__mul24(wf1, y1);
+          const int pf = bpp_clamp(dinv((int)bpp_idiv64(fs, BP_WBITS)), 1, BP_PSCALEm);
+          const uint32_t rnew = (uint32_t)(((unsigned long long)range * ((uint32_t)(BP_PSCALE - pf) << (32 - BP_PBITS))) >> 32);
+          { const uint32_t mb = 0u - (uint32_t)bit; lowc += (unsigned long long)(rnew & mb); range = (range & mb) - (rnew & mb) + (rnew & ~mb); }
+          while (range < 0x01000000u) { range <<= 8; shift_low(); }
+          const int err = (bit << BP_PBITS) - pf;
+          wf0 = bpp_clamp(wf0 + bpp_idiv32(__mul24(bpp_idiv32(__mul24(y0, err), BP_DBITS), 300), BP_DBITS), -BP_WRANGE, BP_WRANGE - 1);
+          wf1 = bpp_clamp(wf1 + bpp_idiv32(__mul24(bpp_idiv32(__mul24(y1, err), BP_DBITS), 300), BP_DBITS), -BP_WRANGE, BP_WRANGE - 1);
+        }
+      }
+    }
+#ifdef BPP_PROF
+    busy += clock64() - tb0;
+#endif
+    __syncthreads();
+  }
+#ifdef BPP_PROF
+  if (blockIdx.x == 0 && lane == 0 && nblk > 0) printf("k_bppipe coder %d stage %d: %lld busy cycles per decision (%d blocks)\n", cod, stage, busy / ((long long)nblk * BPP_B), nblk);
+#endif
+  if (live && stage == BPP_STAGES - 1) {
+    for (int i = 0; i < 5; i++) shift_low();  // RangeCoderSH::Stop, range.cpp:60-63
+    if (lane == 0) sizes[b] = pos;
   }
 }

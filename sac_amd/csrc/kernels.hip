@@ -2333,6 +2333,13 @@ extern "C" int sacopt_launch_bpsize(const BpJob *jobs, int nbuf, int maxn, int m
                                     const int16_t *fwd, const uint16_t *inv, const uint16_t *sse_init, int tscale, int xscale, int32_t *sizes,
                                     hipStream_t st) {
   if (nbuf <= 0) return 0;
+  BpTables tbp = {fwd, inv, sse_init, tscale, xscale};
+  // the stage-pipeline form (bitplane.h): up to 16 workgroup rounds of two coders per CU; beyond that the lane-per-coder forms
+  // move more decisions per CU
+  if (BP_PIPE && nbuf <= BP_PIPE_MAX) {
+    hipLaunchKernelGGL(k_bppipe, dim3((nbuf + BPP_NCOD - 1) / BPP_NCOD), dim3(BPP_NT), 0, st, jobs, nbuf, tbp, sizes);
+    return hipGetLastError() != hipSuccess;
+  }
   const int nblk = (nbuf + 63) / 64;
   if (maxn > 0) hipLaunchKernelGGL(k_bp_transpose, dim3((maxn + 255) / 256, nblk), dim3(256), 0, st, jobs, nbuf, maxn, T);
   BpTables tb = {fwd, inv, sse_init, tscale, xscale};
