@@ -317,8 +317,10 @@ __global__ __launch_bounds__(WPC ? 64 * LPW : 64) void k_bpsize(const BpJob *__r
 // Same integer arithmetic, same order of updates per counter / weight / bin: sizes identical to k_bpsize.
 // branch-free forms of the rounding shifts and clamps (the values of the serial loops are wave-uniform: the compiler keeps them in
 // scalar registers and turned every `x < 0 ? .. : ..` into a scalar branch, ~25 cycles each, twenty per decision)
-__device__ __forceinline__ int bpp_idiv32(int val, int sh) { const int m = val >> 31; return ((((val ^ m) - m) + (1 << (sh - 1))) >> sh ^ m) - m; }
-__device__ __forceinline__ long long bpp_idiv64(long long val, int sh) { const long long m = val >> 63; return ((((val ^ m) - m) + (1ll << (sh - 1))) >> sh ^ m) - m; }
+// idiv_signed (global.h): val < 0 ? -((-val + h) >> s) : (val + h) >> s with h = 2^(s-1). For val < 0 that is
+// ceil((val - h) / 2^s) = (val + h - 1) >> s (arithmetic shift), so both cases are (val + h + (val >> 31)) >> s.
+__device__ __forceinline__ int bpp_idiv32(int val, int sh) { return (val + (1 << (sh - 1)) + (val >> 31)) >> sh; }
+__device__ __forceinline__ long long bpp_idiv64(long long val, int sh) { return (val + (1ll << (sh - 1)) + (val >> 63)) >> sh; }
 __device__ __forceinline__ int bpp_clamp(int v, int lo, int hi) { return max(lo, min(v, hi)); }
 #ifndef BPP_ALLSTORE
 #define BPP_ALLSTORE 1  // stores of wave-uniform values by every lane (no exec-mask branch) instead of lane 0 only
@@ -375,7 +377,8 @@ __global__ __launch_bounds__(BPP_NT) void k_bppipe(const BpJob *__restrict__ job
   const uint32_t xmagic = (uint32_t)((0x100000000ull + (uint32_t)xscale - 1) / (uint32_t)xscale);
   auto divx = [&](int x) -> int { int q = (int)__umulhi((uint32_t)x, xmagic); q -= (q * xscale > x) ? 1 : 0; return q; };
   auto dinv = [&](int x) -> int { return (int)inv[bpp_clamp(x, -(1 << (BP_DBITS - 1)) - 1, 1 << (BP_DBITS - 1)) + (1 << (BP_DBITS - 1)) + 1]; };
-  // S3 / S4 state (registers of the stage's wave)
+  // S2 / S3 / S4 state (registers of the stage's wave)
+  int curmix = -1, cw0 = 0, cw1 = 0, cw2 = 0;  // S2: the mixer used last and its weights
   uint32_t lbreg = 0;
   int wf0 = 0, wf1 = 0;
   uint32_t range = 0xFFFFFFFFu, ffnum = 0;
@@ -468,14 +471,17 @@ __global__ __launch_bounds__(BPP_NT) void k_bppipe(const BpJob *__restrict__ job
           const uint32_t r = __builtin_amdgcn_readlane(rv, j);
           const int bit = r & 1, sig = (r >> 1) & 1, mixctx = (r >> 2) & 7;
           const int x0 = __builtin_amdgcn_readlane(xv0, j), x1 = __builtin_amdgcn_readlane(xv1, j), x2 = __builtin_amdgcn_readlane(xv2, j);
-          int *w = &wts[cod][(mixctx + 8 * (1 - sig)) * 3];
-          const int w0 = w[0], w1 = w[1], w2 = w[2];
-          const long long sum = (long long)__mul24(w0, x0) + (long long)__mul24(w1, x1) + (long long)__mul24(w2, x2);
+          const int mix = (mixctx + 8 * (1 - sig)) * 3;
+          int *w = &wts[cod][mix];
+          if (mix != curmix) { cw0 = w[0]; cw1 = w[1]; cw2 = w[2]; curmix = mix; }  // (written through below: LDS always holds every mixer's weights)
+          const int w0 = cw0, w1 = cw1, w2 = cw2;
+          const long long sum = (long long)(w0) * (x0) + (long long)(w1) * (x1) + (long long)(w2) * (x2);
           const int pd = bpp_clamp(dinv((int)bpp_idiv64(sum, BP_WBITS)), 1, BP_PSCALEm);
           const int err = (bit << BP_PBITS) - pd;
-          const int n0 = bpp_clamp(w0 + bpp_idiv32(__mul24(bpp_idiv32(__mul24(x0, err), BP_DBITS), 800), BP_DBITS), -BP_WRANGE, BP_WRANGE - 1);
-          const int n1 = bpp_clamp(w1 + bpp_idiv32(__mul24(bpp_idiv32(__mul24(x1, err), BP_DBITS), 800), BP_DBITS), -BP_WRANGE, BP_WRANGE - 1);
-          const int n2 = bpp_clamp(w2 + bpp_idiv32(__mul24(bpp_idiv32(__mul24(x2, err), BP_DBITS), 800), BP_DBITS), -BP_WRANGE, BP_WRANGE - 1);
+          const int n0 = bpp_clamp(w0 + bpp_idiv32(__mul24(bpp_idiv32((x0) * (err), BP_DBITS), 800), BP_DBITS), -BP_WRANGE, BP_WRANGE - 1);
+          const int n1 = bpp_clamp(w1 + bpp_idiv32(__mul24(bpp_idiv32((x1) * (err), BP_DBITS), 800), BP_DBITS), -BP_WRANGE, BP_WRANGE - 1);
+          const int n2 = bpp_clamp(w2 + bpp_idiv32(__mul24(bpp_idiv32((x2) * (err), BP_DBITS), 800), BP_DBITS), -BP_WRANGE, BP_WRANGE - 1);
+          cw0 = n0; cw1 = n1; cw2 = n2;
           BPP_ONE { w[0] = n0; w[1] = n1; w[2] = n2; }
           if (lane == j) pdv = (uint16_t)pd;
         }
@@ -504,13 +510,13 @@ __global__ __launch_bounds__(BPP_NT) void k_bppipe(const BpJob *__restrict__ job
           uint32_t *e0 = &ssel[cod][(mymsb * 2 + lb) * 33 + q];
           const uint32_t v0 = e0[0], v1 = e0[1];
           const int pl0 = (int)(v0 & 0xffffu), ph0 = (int)(v1 & 0xffffu);
-          const int ps = bpp_clamp(divx(__mul24(pl0, xscale - pmod) + __mul24(ph0, pmod)), 1, BP_PSCALEm);
+          const int ps = bpp_clamp(divx((pl0) * (xscale - pmod) + (ph0) * (pmod)), 1, BP_PSCALEm);
           auto lcl = [&](uint32_t v) -> uint32_t {  // LinearCounterLimit::update, counter.h:57-65
             int p1 = (int)(v & 0xffffu);
             const int cnt = min((int)(v >> 16) + 1, 1000);
-            const int dv = (int)divt[cnt];
+            const int dv = (int)divt[cnt];  // (computed from a float reciprocal instead: 765 against 523 cycles for this stage)
             const int nb1 = bit - 1;  // 0 / -1
-            const int d = __mul24(p1 + bit * (BP_PSCALE - 2 * p1), dv) >> BP_PBITS;  // bit ? (PSCALE - p1) * dv : p1 * dv
+            const int d = (p1 + bit * (BP_PSCALE - 2 * p1)) * (dv) >> BP_PBITS;  // bit ? (PSCALE - p1) * dv : p1 * dv
             p1 = bpp_clamp(p1 + ((d ^ nb1) - nb1), 1, BP_PSCALEm);
             return (uint32_t)p1 | ((uint32_t)cnt << 16);
           };
@@ -527,14 +533,14 @@ __global__ __launch_bounds__(BPP_NT) void k_bppipe(const BpJob *__restrict__ job
           const uint32_t r = __builtin_amdgcn_readlane(rv, j);
           const int bit = r & 1;
           const int y0 = __builtin_amdgcn_readlane(yv0, j), y1 = __builtin_amdgcn_readlane(yv1, j);
-          const long long fs = (long long)__mul24(wf0, y0) + (long long)__mul24(wf1, y1);
+          const long long fs = (long long)(wf0) * (y0) + (long long)(wf1) * (y1);
           const int pf = bpp_clamp(dinv((int)bpp_idiv64(fs, BP_WBITS)), 1, BP_PSCALEm);
           const uint32_t rnew = (uint32_t)(((unsigned long long)range * ((uint32_t)(BP_PSCALE - pf) << (32 - BP_PBITS))) >> 32);
           { const uint32_t mb = 0u - (uint32_t)bit; lowc += (unsigned long long)(rnew & mb); range = (range & mb) - (rnew & mb) + (rnew & ~mb); }
           while (range < 0x01000000u) { range <<= 8; shift_low(); }
           const int err = (bit << BP_PBITS) - pf;
-          wf0 = bpp_clamp(wf0 + bpp_idiv32(__mul24(bpp_idiv32(__mul24(y0, err), BP_DBITS), 300), BP_DBITS), -BP_WRANGE, BP_WRANGE - 1);
-          wf1 = bpp_clamp(wf1 + bpp_idiv32(__mul24(bpp_idiv32(__mul24(y1, err), BP_DBITS), 300), BP_DBITS), -BP_WRANGE, BP_WRANGE - 1);
+          wf0 = bpp_clamp(wf0 + bpp_idiv32(__mul24(bpp_idiv32((y0) * (err), BP_DBITS), 300), BP_DBITS), -BP_WRANGE, BP_WRANGE - 1);
+          wf1 = bpp_clamp(wf1 + bpp_idiv32(__mul24(bpp_idiv32((y1) * (err), BP_DBITS), 300), BP_DBITS), -BP_WRANGE, BP_WRANGE - 1);
         }
       }
     }
