@@ -3,7 +3,9 @@
 // mixer.h:56-101, sse.h:88-125, domain.h:6-57), i.e. FrameCoder::EncodeMonoFrame_Normal (src/codec.cpp:237-247) without the
 // bytes. Included by kernels.hip.
 //
-// The coder is one adaptive chain per buffer: every binary decision updates the counters, mixers and the SSE stage the next
+// Two forms: k_bppipe (end of this file: a five-stage pipeline per coder, what sacopt_launch_bpsize takes for up to BP_PIPE_MAX
+// buffers) and k_bpsize (a lane or a wave per coder; the first correct version and the A/B partner).
+// k_bpsize: the coder is one adaptive chain per buffer: every binary decision updates the counters, mixers and the SSE stage the next
 // one reads, bit plane after bit plane. Nothing inside a buffer is parallel, so the parallelism is ACROSS buffers -- the
 // candidates x channels x frames of an optimizer round: one lane per buffer, a wave = 64 coders in lockstep. All arithmetic
 // is the reference's integer arithmetic; the only floating point of the original, the stretch / squash tables of LogDomain
