@@ -67,7 +67,8 @@ struct BpTables {
   const uint16_t *sse_init;
   int tscale, xscale;
 };
-// LPW = coders (lanes) per wave.
+// LPW = coders (lanes) per wave. (Since k_bppipe only LPW = 64 is reachable in the product library -- passes of more than
+// BP_PIPE_MAX buffers; the two latency forms are the A/B partners of timing builds with -DBP_PIPE=0.)
 //   64  throughput form: every lane a coder; the SSE maps ((maxbpn+1) x 32 contexts x 264 bytes per coder) live in HBM.
 //   8   latency form, for passes with few buffers (an optimizer round: candidates x channels x frames): the chip has more CUs than
 //       such a pass has waves, so what counts is the time per decision of ONE coder. Eight coders per wave leave room for the SSE

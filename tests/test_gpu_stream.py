@@ -194,12 +194,31 @@ def test_coded_sizes_vs_restated_coder(oracle):
     for k in range(70):   # a second wave, short random buffers
         nb = int(rs.randint(1, 400)); top = int(rs.randint(0, 12))
         bufs.append(rs.randint(0, 1 << (top + 1), nb).astype(np.int32)); mb.append(top)
+    for nb in (63, 64, 65, 128, 129, 191):   # around the edges of k_bppipe's blocks of 64 decisions
+        bufs.append(rs.randint(0, 1 << 9, nb).astype(np.int32)); mb.append(8)
     with sacopt.Context(0) as c:
         got = c.coded_sizes(bufs, mb)
     for i, (b, m) in enumerate(zip(bufs, mb)):
         b = np.ascontiguousarray(b, dtype=np.int32)
         want = oracle.lib.oracle_encode_mono_normal(b.ctypes.data_as(C.c_void_p), C.c_int(len(b)), C.c_int(int(m)), None, C.c_int(0))
         assert got[i] == want, (i, len(b), m, got[i], want)
+
+
+def test_coded_sizes_many_buffers_lane_per_coder_form(oracle):
+    # more than BP_PIPE_MAX (8192) buffers in one pass take k_bpsize<64> (a lane per coder, 64 coders per wave) instead of the
+    # stage pipeline: same sizes
+    import ctypes as C
+    rs = np.random.RandomState(11)
+    bufs, mb = [], []
+    for k in range(8200):
+        nb = int(rs.randint(1, 13)); top = int(rs.randint(0, 6))
+        bufs.append(rs.randint(0, 1 << (top + 1), nb).astype(np.int32)); mb.append(top)
+    with sacopt.Context(0) as c:
+        got = c.coded_sizes(bufs, mb)
+    for i in list(range(0, 8200, 37)) + [8199]:
+        b = bufs[i]
+        want = oracle.lib.oracle_encode_mono_normal(b.ctypes.data_as(C.c_void_p), C.c_int(len(b)), C.c_int(int(mb[i])), None, C.c_int(0))
+        assert got[i] == want, (i, len(b), mb[i], got[i], want)
 
 
 @pytest.mark.parametrize("cost_fn,prof,lens", [(1, 2, [4096, 3000]), (1, 1, [5000]), (2, 2, [4096, 3000]), (2, 0, [2500])])
