@@ -38,6 +38,7 @@ sys.path.insert(0, ROOT)
 FRAME = 176400            # 4 s @ 44.1 kHz (src/codec.cpp:533)
 NFRAMES = 15              # 60 s clip (configs[2])
 TRACK_FRAMES = 75         # 5-minute track (configs[3])
+L1C_FRAMES = 48           # sacopt.cpp: calls of up to this many frames run the full-frame pass on k_lms1c (two workgroups per frame)
 FLOPS_LMS1 = 2 * (11 * 1920 + 1)   # algorithmic FP64 flops per stereo sample of LMSADA2(1280,640) x 2 ch
 FLOPS_UNIT_HIGH = 58934            # per candidate stereo sample, whole high cascade
 FP64_VECTOR_PEAK_TFLOPS = 78.6     # MI355X datasheet vector FP64
@@ -172,20 +173,23 @@ def apply_params_extra(ctx, torch, sacopt, b, nfr):
             "ms": 1e3 * dt, "value": nfr * FRAME / dt, "unit": "samples/s"}
 
 
-def pmc_traffic():
+def pmc_traffic(full_chip=False):
     """HBM bytes per launch of the dominant kernel, (bytes, file): a STORED figure from the newest committed PMC pass of this
     same command (profiles/rNN*_pmc_hbm.json, highest round prefix; FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, collected
-    in rocprofv3 --pmc runs of their own) -- a bench run cannot read the counters itself. (None, None) if not collected."""
+    in rocprofv3 --pmc runs of their own) -- a bench run cannot read the counters itself. full_chip: the 75-frame call's
+    two-channel kernel from profiles/rNN*_pmc_75frames.json. (None, None) if not collected."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]*_pmc_hbm.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]*_pmc_75frames.json" if full_chip else "r[0-9][0-9]*_pmc_hbm.json")))
     for path in reversed(files):
         try:
             with open(path) as f:
                 ks = json.load(f)["kernels"]
             for name, v in ks.items():
-                if name.startswith("k_lms1c"):
+                if full_chip and name.startswith("k_lms2"):
+                    return v["hbm_bytes"] / v["dispatches"], os.path.relpath(path, ROOT)
+                if not full_chip and name.startswith("k_lms1c"):
                     return v["hbm_bytes_per_dispatch"], os.path.relpath(path, ROOT)
-        except (OSError, KeyError, ValueError):
+        except (OSError, KeyError, ValueError, ZeroDivisionError):
             continue
     return None, None
 
@@ -324,8 +328,9 @@ def main():
         units_per_launch = lms_units / max(lms_launches, 1)
         achieved = units_per_launch * FLOPS_LMS1 / avg_launch_s / 1e12 if lms_launches else 0.0
         nfr_call = min(nfr, per_call)
-        wgs = 2 * nfr_call if nfr_call <= 20 else nfr_call   # per-channel kernel: two workgroups per frame; two-channel kernel: one
-        traffic, traffic_file = pmc_traffic() if nfr_call <= 20 else (None, None)
+        one_ch = nfr_call <= L1C_FRAMES   # the full-frame pass runs k_lms1c (sacopt.cpp: L1C_FRAMES), else the two-channel k_lms2
+        wgs = 2 * nfr_call if one_ch else nfr_call   # per-channel kernel: two workgroups per frame; two-channel kernel: one
+        traffic, traffic_file = pmc_traffic() if nfr_call == NFRAMES else (pmc_traffic(True) if nfr_call == TRACK_FRAMES else (None, None))
         if world == 1:
             workload = (f"{nfr * 4} s synthetic 16-bit 44.1 kHz stereo clip ({nfr} frames x {FRAME}), high profile, full optimizer population "
                         f"({cand} GetCost per frame) + final full-frame predict (BASELINE configs[2]); range coding and file I/O excluded")
@@ -343,18 +348,18 @@ def main():
                        "rsqrt_bits": int(rsq_bits), "rsqrt_table_sha256_16": rsq_sha, "host_cpu": host_cpu_model(),
                        "parallelism": f"frames sharded x{world}, no collective on the data path" + ("" if world == 1 else f"; result rows gathered over {args.backend}"), "checked_against_separate_calls": verified},
             "algorithmic_tflops_whole_path": cand_units * args.steps * FLOPS_UNIT_HIGH / dt / 1e12,
-            "roofline": {"bound": "mfma", "kernel": "k_lms1c" if nfr_call <= 20 else "k_lms<1280,640,512,8,2048,true> / k_lms1c (tail chunks)",
+            "roofline": {"bound": "mfma", "kernel": "k_lms1c" if one_ch else "k_lms2 (two-channel (1280,640) kernel: full-frame pass and the optimizer's heavy rounds)",
                          "note": "FP64 compute bound (78.6 TFLOP/s vector = matrix FP64 peak); the real ceiling is the dependent-add "
                                  "latency of the serial 1920-term sums, the matrix pipe is used as an exact f64 adder, not a GEMM",
                          "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic,
                          "traffic_source": (traffic_file + " (stored PMC pass of this command, not this run)") if traffic_file else None,
-                         "workgroups_per_launch": wgs if nfr_call <= 20 else None,
-                         "frac_of_occupied_cus": achieved / (FP64_VECTOR_PEAK_TFLOPS * min(wgs, 256) / 256.0) if nfr_call <= 20 else None,
+                         "workgroups_per_launch": wgs if one_ch else None,
+                         "frac_of_occupied_cus": achieved / (FP64_VECTOR_PEAK_TFLOPS * min(wgs, 256) / 256.0) if one_ch else None,
                          "avg_launch_ms": 1e3 * avg_launch_s, "launches": lms_launches,
                          "units_per_launch": units_per_launch, "flops_per_unit": FLOPS_LMS1,
                          # serial latency of the dominant kernel: launch duration over the samples one chain advances in it
-                         "cycles_per_sample_at_2.4GHz": (avg_launch_s * 2.4e9 / (units_per_launch / nfr_call)) if (lms_launches and nfr_call <= 20) else None},
+                         "cycles_per_sample_at_2.4GHz": (avg_launch_s * 2.4e9 / (units_per_launch / nfr_call)) if (lms_launches and one_ch) else None},
         }
         if verified is False:
             line["error"] = "the overlapped call's results differ from FrameCoder::Optimize / PredictStereoFrame run separately: no value reported"
