@@ -584,13 +584,19 @@ __device__ __forceinline__ double spec_exact_sum(uint32_t prods_addr, int (*sJ)[
 #define H_SPLIT 224  // (256,128) stage: terms summed from +0 by wave 0 (56 MFMA steps); the candidate waves guess that sum first, so they get the shorter rest (40 steps)
 #endif
 static_assert(H_SPLIT == 192 || H_SPLIT == 224, "chains exist for 192 + 192 and 224 + 160 terms");
+#ifndef H_HALVES
+#define H_HALVES 1  // (256,128): the two-halves exact-hit sum (0: the undivided 96-step chain; A/B switch)
+#endif
+#ifndef H_PLAIN_MIN
+#define H_PLAIN_MIN 512  // (30 / 40 frames = 330 / 440 chains are still 1-2 % faster with the halves)
+#endif
 #ifndef LMS_HALVES_WAVES
 #define LMS_HALVES_WAVES 2  // candidate waves of the (256,128) stage's second half: 32 candidates per channel each
 #endif
 #ifndef LMS_TABG
 #define LMS_TABG 1  // 75-frame encode call, same run: 1276 -> 1251 ms; 2 (also the (256,128) stage: 768 look-ups per sample through the L1) 1284 ms
 #endif
-template <int S, int D, int NT, int R, int RL, bool SPEC, int CHP = LMS_CHUNK>
+template <int S, int D, int NT, int R, int RL, bool SPEC, int CHP = LMS_CHUNK, bool HALV = true>
 __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, const uint16_t *__restrict__ gtab,
                                             int bits, int ct0, int clen) {
   constexpr int T = S + D, T4 = T / 4, M = RL - 1, CH = CHP;  // CH: samples staged per refill (divides LMS_CHUNK, the unit of the host's chunk edges)
@@ -624,7 +630,7 @@ __global__ __launch_bounds__(NT) void k_lms(const LmsJob *__restrict__ jobs, con
   // candidates in ONE chain of 48 steps per wave). If the exact first half IS one of the candidates, bit for bit, that candidate's
   // output is the exact left-to-right sum of all 384 terms; if not, wave 0 sums the second half from the exact value
   // (48 more steps, as long as the undivided chain). Exactness never rests on the guess.
-  constexpr bool HALVES = !SPEC && T == 384;
+  constexpr bool HALVES = H_HALVES && HALV && !SPEC && T == 384;
   constexpr bool ALLVALID = !SPEC && NT * R == 2 * T;  // every tap slot is used: no per-slot validity tests (H_FAST)
   __shared__ double hX1[2], hOut[2][64], hGb[2], hIu[2], hU[2], hP2[2];
 
@@ -2215,6 +2221,11 @@ extern "C" int sacopt_launch_lms(int S, int D, const LmsJob *jobs, int njobs, co
     else if (S == 8 && D == 4) hipLaunchKernelGGL((k_lms<8, 4, 64, 1, 1024, false>), dim3(njobs), dim3(64), 0, st, jobs, tab, bits, ct0, clen);
     else return 1;
   }
+  // (256,128): the two-halves sum is 136-139 MFMAs per stereo sample for a chain of 56 + look-up instead of 96 dependent steps -- right
+  // while a launch is bound by the latency of its chains, wrong when the chip is full and four of these workgroups share a CU's
+  // matrix pipes (packed four to a CU the stage costs 2.0k CU-cycles per stereo sample): launches of more than H_PLAIN_MIN chains
+  // take the undivided 96-step chain (same-run A/B on the encode call: 75 frames 1248 -> 1223 ms; 15 frames 401 -> 432 ms the other way)
+  else if (S == 256 && D == 128 && njobs > H_PLAIN_MIN) hipLaunchKernelGGL((k_lms<256, 128, H2_NT, H2_R, 512, false, 128, false>), dim3(njobs), dim3(H2_NT), 0, st, jobs, tab, bits, ct0, clen);
   else if (S == 256 && D == 128) hipLaunchKernelGGL((k_lms<256, 128, H2_NT, H2_R, 512, false, 128>), dim3(njobs), dim3(H2_NT), 0, st, jobs, tab, bits, ct0, clen);
   else if (S == 32 && D == 16) hipLaunchKernelGGL((k_lms<32, 16, 64, 2, 256, false, 128>), dim3(njobs), dim3(64), 0, st, jobs, tab, bits, ct0, clen);
   else if (S == 8 && D == 4) hipLaunchKernelGGL((k_lms<8, 4, 64, 1, 256, false, 128>), dim3(njobs), dim3(64), 0, st, jobs, tab, bits, ct0, clen);

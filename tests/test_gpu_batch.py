@@ -34,11 +34,12 @@ def _ragged_frames(count, seed):
 
 
 def test_large_batch_encode_and_optimize_vs_oracle(rsqrt_table, oracle):
-    # FrameCoder::Predict with Optimize enabled (codec.cpp:442-461) for 44 frames in ONE call
-    frames = _ragged_frames(44, 3)
+    # FrameCoder::Predict with Optimize enabled (codec.cpp:442-461) for 52 frames in ONE call (520-624 chains per round: beyond
+    # 512 the (256,128) stage takes its undivided-chain instance, beyond 48 frames the full-frame pass the two-channel kernel)
+    frames = _ragged_frames(52, 3)
     with sacopt.Context(0, *rsqrt_table) as c:
         best_e, outs = c.encode(2, frames, maps=True)
-        best_o, traces, rows = c.optimize(2, frames)       # 44 x 11 = 484 chains in the heavy rounds
+        best_o, traces, rows = c.optimize(2, frames)       # 52 x 10..12 chains per round
         full = c.predict(2, frames, maps=True)
         assert list(rows) == [84] * len(frames)
         assert same_bits(best_e, best_o)
@@ -46,7 +47,7 @@ def test_large_batch_encode_and_optimize_vs_oracle(rsqrt_table, oracle):
             for k in KEYS:
                 assert np.array_equal(outs[f][k], full[f][k]), (f, k)
         # the same frames in calls of one and of three (k_lms1c, split stream set, reserved CUs): identical results
-        for f in (0, 17, 43):
+        for f in (0, 17, 51):
             b1, o1 = c.encode(2, [frames[f]], maps=True)
             assert same_bits(b1[0], best_e[f]), f
             for k in KEYS:
