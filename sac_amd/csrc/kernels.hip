@@ -931,6 +931,8 @@ __device__ double s2occ[4 * 1024];
 __global__ __launch_bounds__(S2_NT, 4) void k_lms2(const LmsJob *__restrict__ jobs, const uint16_t *__restrict__ gtab, int bits, int ct0, int clen) {
   constexpr int S = 1280, T = 1920, NT = S2_NT, CH = S2_CH, HL = S2_HL, R = 8;
   constexpr int SEG = L1_SEG, SEGP = L1_SEGP, NSEG = 15, TP = 16 * SEGP;
+  // (the table through the vector L1 instead -- 60 KB of LDS, so that a pair and a (256,128) workgroup fit a CU -- was measured: 3840
+  // look-ups per sample are too many for the L1, 75 frames 1215 -> 1285 ms)
   __shared__ __attribute__((aligned(256))) uint16_t tab[RSQ_LDS_MAX];
 #ifdef S2_PAD  // (timing builds: so much more LDS that only one workgroup fits a CU)
   __shared__ double s2pad[S2_PAD];
