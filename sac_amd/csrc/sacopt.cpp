@@ -31,6 +31,15 @@ int sacopt_lms_variant(int S, int D, int njobs, int bits, int limit);
 // 30: 676 / 705, 40: 805 / 840, 50: 966 / 972, 60: 1105 / 1076, 75: 1334 / 1284 (beyond ~50 frames the pass shares the chip with the
 // optimizer's rounds and the call is throughput-bound: the two-channel kernel is cheaper per CU). Optimizer windows: up to 20 chains
 // per launch (up to 96 chains on k_lms1c changed nothing for encode calls of 2..15 frames: the full-frame pass bounds them).
+#ifndef LEAD_SPLIT_MIN
+#define LEAD_SPLIT_MIN 512
+#endif
+#ifndef LEAD_SPLIT_WAYS
+#define LEAD_SPLIT_WAYS 3  // 75 frames, same run: 1 sequence 1212 ms, 2: 1150, 3: 1132, 4: 1137
+#endif
+#ifndef LEAD_SPLIT_ANY
+#define LEAD_SPLIT_ANY 0  // 1: also rounds led by another LMS stage
+#endif
 #ifndef ROUND_CHUNKS_BIG
 #define ROUND_CHUNKS_BIG 16  // chunks per optimizer window when a round's lead launch has more workgroups than the chip has CUs
 #endif
@@ -84,6 +93,7 @@ struct sacopt_ctx {
   hipStream_t up = nullptr;                // stream of upload() (NULL: st); the full-frame pipeline stages its job tables on sB
   hipStream_t sAall = nullptr;             // lead stage of the full-frame pass when it has more workgroups than sA's reserved CUs
   hipStream_t sD = nullptr;                // final-pass pipeline: stages behind the second LMS stage (may be NULL)
+  hipStream_t sL2[3] = {nullptr, nullptr, nullptr};  // further lead streams of the optimizer's rounds in large batches (every CU; see eval_chains)
   // Events are created once and reused from call to call (a 15-frame encode call records several hundred): two pools, with
   // and without timing, handed out in order and taken back as a whole by begin_call once every stream is idle.
   std::vector<hipEvent_t> ev_timed, ev_plain;
@@ -359,6 +369,8 @@ extern "C" int sacopt_create(int device, const float *rsqrt_tab, int rsqrt_bits,
           // that two lead workgroups share every CU there -- 75 frames 2050 / 1480 / 1445 against 1280 ms: the lead launches do get
           // 1.46x as much out of a CU, but the followers need more than a quarter of the chip.)
           for (int i = 0; i < 5 && ok; i++) ok = hipExtStreamCreateWithCUMask(&c->big[i], words, mall.data()) == hipSuccess;
+          for (int i = 0; i < 3 && ok; i++)
+            if (hipExtStreamCreateWithCUMask(&c->sL2[i], words, mall.data()) != hipSuccess) { (void)hipGetLastError(); c->sL2[i] = nullptr; break; }
           if (!ok) {
             (void)hipGetLastError();
             for (hipStream_t &p : c->big) if (p) { (void)hipStreamDestroy(p); p = nullptr; }
@@ -427,7 +439,7 @@ extern "C" void sacopt_destroy(sacopt_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   for (hipStream_t q : {c->st, c->sA, c->sAall, c->sB, c->sC, c->sD, c->sE, c->split[0], c->split[1], c->split[2], c->split[3], c->split[4],
-                       c->big[0], c->big[1], c->big[2], c->big[3], c->big[4]})
+                       c->big[0], c->big[1], c->big[2], c->big[3], c->big[4], c->sL2[0], c->sL2[1], c->sL2[2]})
     if (q) (void)hipStreamSynchronize(q);
   for (hipEvent_t e : c->ev_timed) (void)hipEventDestroy(e);
   for (hipEvent_t e : c->ev_plain) (void)hipEventDestroy(e);
@@ -448,6 +460,7 @@ extern "C" void sacopt_destroy(sacopt_ctx *c) {
   if (c->sE) (void)hipStreamDestroy(c->sE);
   for (hipStream_t p : c->split) if (p) (void)hipStreamDestroy(p);
   for (hipStream_t p : c->big) if (p) (void)hipStreamDestroy(p);
+  for (hipStream_t p : c->sL2) if (p) (void)hipStreamDestroy(p);
   if (c->st) (void)hipStreamDestroy(c->st);
   delete c;
 }
@@ -534,7 +547,7 @@ static int begin_call(sacopt_ctx *c) {
   c->err.clear();
   // a call that failed half-way may have left work in flight on the pipeline streams; the arena is about to be reused
   for (hipStream_t s : {c->st, c->sA, c->sAall, c->sB, c->sC, c->sD, c->sE, c->split[0], c->split[1], c->split[2], c->split[3], c->split[4],
-                       c->big[0], c->big[1], c->big[2], c->big[3], c->big[4]})
+                       c->big[0], c->big[1], c->big[2], c->big[3], c->big[4], c->sL2[0], c->sL2[1], c->sL2[2]})
     if (s) HIPCK(c, hipStreamSynchronize(s));
   // nothing is in flight any more: the staging memory of the previous call can be reused (several blocks -> one of their size)
   if (c->pins.size() > 1) {
@@ -857,6 +870,19 @@ static int eval_chains(sacopt_ctx *c, const ProfDesc &pd, const std::vector<DevF
   HP_MARK(hp2);
   std::vector<void *> d_jobs(nstage, nullptr);
   for (int s = lead; s < nstage; s++) d_jobs[s] = d_tables + o_jobs[s];
+  // Large batches: the lead stage's chains in two halves on two streams (LEAD_SPLIT_MIN chains or more: more workgroups than the chip
+  // holds at once). A chunk launch ends with its slowest workgroup; with one sequence of launches the chip runs half empty at the end
+  // of every chunk, with two that drift apart one's tail is the other's head.
+  int nseq = 1;  // launch sequences of the lead stage
+  if (LEAD_SPLIT_MIN > 0 && c->st == c->big[0] && carry && lead <= pd.nlms && (LEAD_SPLIT_ANY || pd.lms[lead - 1].S == 1280) && n_jobs[lead] >= LEAD_SPLIT_MIN)
+    while (nseq < LEAD_SPLIT_WAYS && c->sL2[nseq - 1]) nseq++;
+  const bool two = nseq > 1;
+  if (two) {
+    hipEvent_t e0;
+    TAKE_EVENT(c, e0, false);
+    HIPCK(c, hipEventRecord(e0, c->st));  // tables are up, the round before is over
+    for (int q = 1; q < nseq; q++) HIPCK(c, hipStreamWaitEvent(c->sL2[q - 1], e0, 0));
+  }
   for (int k = 0; k < nchunk; k++) {
     const long long units = units_all[k];
     const int ct0 = k * chunk, clen = carry ? chunk : 0;  // (a single launch covers the jobs' own spans)
@@ -876,11 +902,22 @@ static int eval_chains(sacopt_ctx *c, const ProfDesc &pd, const std::vector<DevF
             TAKE_EVENT(c, b, true);
             HIPCK(c, hipEventRecord(a, st));
           }
-          if (sacopt_launch_lms(sd.S, sd.D, (const LmsJob *)d_jobs[s], n_jobs[s], c->d_tab, c->bits, st, L1C_WINDOW, ct0, clen)) { c->err = "k_lms launch failed"; return 1; }
+          const int nA = (two && s == lead) ? n_jobs[s] / nseq : n_jobs[s];
+          if (sacopt_launch_lms(sd.S, sd.D, (const LmsJob *)d_jobs[s], nA, c->d_tab, c->bits, st, L1C_WINDOW, ct0, clen)) { c->err = "k_lms launch failed"; return 1; }
           if (dominant) {
             HIPCK(c, hipEventRecord(b, st));
             c->lms_ev.push_back({a, b});
-            c->lms_units += units;
+            c->lms_units += units * nA / n_jobs[s];
+          }
+          if (nA < n_jobs[s]) {  // the other parts on the further lead streams: the launch sequences drift apart, one's tail fills with another's head
+            for (int q = 1; q < nseq; q++) {
+              const int j0 = nA * q, j1 = q == nseq - 1 ? n_jobs[s] : nA * (q + 1);
+              if (sacopt_launch_lms(sd.S, sd.D, (const LmsJob *)d_jobs[s] + j0, j1 - j0, c->d_tab, c->bits, c->sL2[q - 1], L1C_WINDOW, ct0, clen)) { c->err = "k_lms launch failed"; return 1; }
+              hipEvent_t e2;
+              TAKE_EVENT(c, e2, false);
+              HIPCK(c, hipEventRecord(e2, c->sL2[q - 1]));
+              HIPCK(c, hipStreamWaitEvent(lead < nstage - 1 ? c->sC : c->st, e2, 0));
+            }
           }
         } else {
           if (sacopt_launch_mix(pd.nlms, (const MixJob *)d_jobs[s], n_jobs[s], st, ct0, clen)) { c->err = "k_mix launch failed"; return 1; }
