@@ -32,7 +32,7 @@ int sacopt_lms_variant(int S, int D, int njobs, int bits, int limit);
 // optimizer's rounds and the call is throughput-bound: the two-channel kernel is cheaper per CU). Optimizer windows: up to 20 chains
 // per launch (up to 96 chains on k_lms1c changed nothing for encode calls of 2..15 frames: the full-frame pass bounds them).
 #ifndef LEAD_SPLIT_MIN
-#define LEAD_SPLIT_MIN 512
+#define LEAD_SPLIT_MIN 256  // 34 / 40 / 50 frames (340-550 chains per round), same run: 738 -> 653, 793 -> 733, 925 -> 821 ms
 #endif
 #ifndef LEAD_SPLIT_WAYS
 #define LEAD_SPLIT_WAYS 3  // 75 frames, same run: 1 sequence 1212 ms, 2: 1150, 3: 1132, 4: 1137
@@ -93,7 +93,10 @@ struct sacopt_ctx {
   hipStream_t up = nullptr;                // stream of upload() (NULL: st); the full-frame pipeline stages its job tables on sB
   hipStream_t sAall = nullptr;             // lead stage of the full-frame pass when it has more workgroups than sA's reserved CUs
   hipStream_t sD = nullptr;                // final-pass pipeline: stages behind the second LMS stage (may be NULL)
-  hipStream_t sL2[3] = {nullptr, nullptr, nullptr};  // further lead streams of the optimizer's rounds in large batches (every CU; see eval_chains)
+  hipStream_t sL2[2] = {nullptr, nullptr};  // further lead streams of the optimizer's rounds in large batches (every CU; see eval_chains)
+  // (Every CU-masked stream is a hardware queue of its own, and the chip has a fixed number of them: with these 19 everything
+  // measured here is fine (tools/queue_cliff.sh: a process may hold 22), with 23 -- the same lead sequences for the default stream set -- EVERY call was 1.5x slower,
+  // 15 frames 399 -> 600 ms: the queues are time-sliced once they outnumber the hardware's. Do not add streams; reuse.)
   // Events are created once and reused from call to call (a 15-frame encode call records several hundred): two pools, with
   // and without timing, handed out in order and taken back as a whole by begin_call once every stream is idle.
   std::vector<hipEvent_t> ev_timed, ev_plain;
@@ -368,8 +371,9 @@ extern "C" int sacopt_create(int device, const float *rsqrt_tab, int rsqrt_bits,
           // (Measured and not adopted: the optimizer's follower streams on 1 / 2 / 3 XCDs of their own, its lead stream on the others, so
           // that two lead workgroups share every CU there -- 75 frames 2050 / 1480 / 1445 against 1280 ms: the lead launches do get
           // 1.46x as much out of a CU, but the followers need more than a quarter of the chip.)
+          // (big[3] on big[1]'s stream -- one hardware queue less, see sL2 -- was measured: 40 frames 733 -> 851 ms, 75 frames 1127 -> 1194)
           for (int i = 0; i < 5 && ok; i++) ok = hipExtStreamCreateWithCUMask(&c->big[i], words, mall.data()) == hipSuccess;
-          for (int i = 0; i < 3 && ok; i++)
+          for (int i = 0; i < 2 && ok; i++)
             if (hipExtStreamCreateWithCUMask(&c->sL2[i], words, mall.data()) != hipSuccess) { (void)hipGetLastError(); c->sL2[i] = nullptr; break; }
           if (!ok) {
             (void)hipGetLastError();
@@ -439,7 +443,7 @@ extern "C" void sacopt_destroy(sacopt_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   for (hipStream_t q : {c->st, c->sA, c->sAall, c->sB, c->sC, c->sD, c->sE, c->split[0], c->split[1], c->split[2], c->split[3], c->split[4],
-                       c->big[0], c->big[1], c->big[2], c->big[3], c->big[4], c->sL2[0], c->sL2[1], c->sL2[2]})
+                       c->big[0], c->big[1], c->big[2], c->big[3], c->big[4], c->sL2[0], c->sL2[1]})
     if (q) (void)hipStreamSynchronize(q);
   for (hipEvent_t e : c->ev_timed) (void)hipEventDestroy(e);
   for (hipEvent_t e : c->ev_plain) (void)hipEventDestroy(e);
@@ -547,7 +551,7 @@ static int begin_call(sacopt_ctx *c) {
   c->err.clear();
   // a call that failed half-way may have left work in flight on the pipeline streams; the arena is about to be reused
   for (hipStream_t s : {c->st, c->sA, c->sAall, c->sB, c->sC, c->sD, c->sE, c->split[0], c->split[1], c->split[2], c->split[3], c->split[4],
-                       c->big[0], c->big[1], c->big[2], c->big[3], c->big[4], c->sL2[0], c->sL2[1], c->sL2[2]})
+                       c->big[0], c->big[1], c->big[2], c->big[3], c->big[4], c->sL2[0], c->sL2[1]})
     if (s) HIPCK(c, hipStreamSynchronize(s));
   // nothing is in flight any more: the staging memory of the previous call can be reused (several blocks -> one of their size)
   if (c->pins.size() > 1) {
@@ -875,7 +879,7 @@ static int eval_chains(sacopt_ctx *c, const ProfDesc &pd, const std::vector<DevF
   // of every chunk, with two that drift apart one's tail is the other's head.
   int nseq = 1;  // launch sequences of the lead stage
   if (LEAD_SPLIT_MIN > 0 && c->st == c->big[0] && carry && lead <= pd.nlms && (LEAD_SPLIT_ANY || pd.lms[lead - 1].S == 1280) && n_jobs[lead] >= LEAD_SPLIT_MIN)
-    while (nseq < LEAD_SPLIT_WAYS && c->sL2[nseq - 1]) nseq++;
+    while (nseq < LEAD_SPLIT_WAYS && nseq - 1 < 2 && c->sL2[nseq - 1]) nseq++;
   const bool two = nseq > 1;
   if (two) {
     hipEvent_t e0;
