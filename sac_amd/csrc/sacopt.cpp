@@ -34,6 +34,9 @@ int sacopt_lms_variant(int S, int D, int njobs, int bits, int limit);
 #ifndef LEAD_SPLIT_MIN
 #define LEAD_SPLIT_MIN 256  // 34 / 40 / 50 frames (340-550 chains per round), same run: 738 -> 653, 793 -> 733, 925 -> 821 ms
 #endif
+#ifndef LEAD_SPLIT_DEFSET
+#define LEAD_SPLIT_DEFSET 1
+#endif
 #ifndef LEAD_SPLIT_WAYS
 #define LEAD_SPLIT_WAYS 3  // 75 frames, same run: 1 sequence 1212 ms, 2: 1150, 3: 1132, 4: 1137
 #endif
@@ -878,14 +881,19 @@ static int eval_chains(sacopt_ctx *c, const ProfDesc &pd, const std::vector<DevF
   // holds at once). A chunk launch ends with its slowest workgroup; with one sequence of launches the chip runs half empty at the end
   // of every chunk, with two that drift apart one's tail is the other's head.
   int nseq = 1;  // launch sequences of the lead stage
-  if (LEAD_SPLIT_MIN > 0 && c->st == c->big[0] && carry && lead <= pd.nlms && (LEAD_SPLIT_ANY || pd.lms[lead - 1].S == 1280) && n_jobs[lead] >= LEAD_SPLIT_MIN)
-    while (nseq < LEAD_SPLIT_WAYS && nseq - 1 < 2 && c->sL2[nseq - 1]) nseq++;
+  // streams for the further sequences: sL2 (every CU) with the large-batch set; with the default set (17..32 frames) two idle streams
+  // of the small-batch set, whose 192 CUs are a subset of the default set's 224 (no new hardware queue: see sL2)
+  hipStream_t xl[2] = {nullptr, nullptr};
+  if (c->big[0] && c->st == c->big[0]) { xl[0] = c->sL2[0]; xl[1] = c->sL2[1]; }
+  else if (LEAD_SPLIT_DEFSET && c->split[0] && c->st != c->split[0]) { xl[0] = c->split[0]; xl[1] = c->split[2]; }
+  if (LEAD_SPLIT_MIN > 0 && carry && lead <= pd.nlms && (LEAD_SPLIT_ANY || pd.lms[lead - 1].S == 1280) && n_jobs[lead] >= LEAD_SPLIT_MIN)
+    while (nseq < LEAD_SPLIT_WAYS && nseq - 1 < 2 && xl[nseq - 1]) nseq++;
   const bool two = nseq > 1;
   if (two) {
     hipEvent_t e0;
     TAKE_EVENT(c, e0, false);
     HIPCK(c, hipEventRecord(e0, c->st));  // tables are up, the round before is over
-    for (int q = 1; q < nseq; q++) HIPCK(c, hipStreamWaitEvent(c->sL2[q - 1], e0, 0));
+    for (int q = 1; q < nseq; q++) HIPCK(c, hipStreamWaitEvent(xl[q - 1], e0, 0));
   }
   for (int k = 0; k < nchunk; k++) {
     const long long units = units_all[k];
@@ -916,10 +924,10 @@ static int eval_chains(sacopt_ctx *c, const ProfDesc &pd, const std::vector<DevF
           if (nA < n_jobs[s]) {  // the other parts on the further lead streams: the launch sequences drift apart, one's tail fills with another's head
             for (int q = 1; q < nseq; q++) {
               const int j0 = nA * q, j1 = q == nseq - 1 ? n_jobs[s] : nA * (q + 1);
-              if (sacopt_launch_lms(sd.S, sd.D, (const LmsJob *)d_jobs[s] + j0, j1 - j0, c->d_tab, c->bits, c->sL2[q - 1], L1C_WINDOW, ct0, clen)) { c->err = "k_lms launch failed"; return 1; }
+              if (sacopt_launch_lms(sd.S, sd.D, (const LmsJob *)d_jobs[s] + j0, j1 - j0, c->d_tab, c->bits, xl[q - 1], L1C_WINDOW, ct0, clen)) { c->err = "k_lms launch failed"; return 1; }
               hipEvent_t e2;
               TAKE_EVENT(c, e2, false);
-              HIPCK(c, hipEventRecord(e2, c->sL2[q - 1]));
+              HIPCK(c, hipEventRecord(e2, xl[q - 1]));
               HIPCK(c, hipStreamWaitEvent(lead < nstage - 1 ? c->sC : c->st, e2, 0));
             }
           }

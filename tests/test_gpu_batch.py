@@ -65,6 +65,26 @@ def test_large_batch_encode_and_optimize_vs_oracle(rsqrt_table, oracle):
                 assert np.array_equal(outs[f][k], ref[k]), (f, k)
 
 
+def test_mid_batch_default_stream_set_vs_oracle(rsqrt_table, oracle):
+    # 26 frames: the default stream set (17..32 frames) with 260-312 chains per round -- the lead stage's chains go out as three
+    # launch sequences, two of them on idle streams of the small-batch set; the full-frame pass runs k_lms1c on sAall
+    frames = _ragged_frames(26, 5)
+    with sacopt.Context(0, *rsqrt_table) as c:
+        best_e, outs = c.encode(2, frames, maps=True)
+        best_o, traces, rows = c.optimize(2, frames)
+        assert list(rows) == [84] * len(frames)
+        assert same_bits(best_e, best_o)
+        b3, t3, _ = c.optimize(2, frames[7:10])
+        assert same_bits(b3, best_o[7:10]) and all(same_bits(t3[i], traces[7 + i]) for i in range(3))
+        for f in (3, 25):
+            L, R = frames[f]
+            ob, ot = oracle.optimize(2, L, R)
+            assert same_bits(best_o[f], ob) and same_bits(traces[f], ot), f
+            ref = oracle.predict(2, L, R, maps=True)
+            for k in KEYS:
+                assert np.array_equal(outs[f][k], ref[k]), (f, k)
+
+
 def test_large_batch_normal_profile_vs_oracle(rsqrt_table, oracle):
     # the normal profile's lead stage is (256,128): same batch logic, other kernels
     frames = _ragged_frames(40, 4)
