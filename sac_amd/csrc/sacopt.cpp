@@ -369,7 +369,12 @@ extern "C" int sacopt_create(int device, const float *rsqrt_tab, int rsqrt_bits,
         // Third set for large batches (big[]: st, sB, sC, sD, sE on EVERY CU): with more lead workgroups than CUs nothing is
         // latency-bound any more, the full-frame pass's lead stage runs on sAall, and 32 CUs kept free for it would idle once it
         // has finished (75 frames: 12 % of the chip from the optimizer's third round on)
-        if (masked) {
+#ifdef SACOPT_ABLATE
+        const bool no_big = getenv("SACOPT_NOBIG") != nullptr;  // timing: seven hardware queues fewer
+#else
+        const bool no_big = false;
+#endif
+        if (masked && !no_big) {
           bool ok = true;
           // (Measured and not adopted: the optimizer's follower streams on 1 / 2 / 3 XCDs of their own, its lead stream on the others, so
           // that two lead workgroups share every CU there -- 75 frames 2050 / 1480 / 1445 against 1280 ms: the lead launches do get
