@@ -128,6 +128,16 @@ int sacopt_optimize_frames(sacopt_ctx *ctx, int profile, int nframes, const saco
 int sacopt_encode_frames(sacopt_ctx *ctx, int profile, int nframes, const sacopt_frame *frames,
                          const double *prof, int ncoef_loop, double *best, sacopt_residuals *out);
 
+/* ---- FrameCoder::Predict with the optimiser's result USED  src/codec.cpp:442-461 ---- */
+/* What :455-459 would be with `PredictStereoFrame(optprofile, ...)`: per frame Optimize(optprofile) over the first
+ * ncoef_loop (>= 1) coefficients -> best[f*ncoef..], then PredictStereoFrame with those values -> out[f]. Same results as
+ * sacopt_optimize_frames followed by sacopt_predict_stereo_frames(coefs = best), in one call: the optimiser fixes the
+ * coefficients in order (:389-406), so each part of the full-frame pass starts as soon as its own parameters are final
+ * instead of after the last round. The stream such frames belong to carries per-frame parameters (sac_amd/host/sacfile.h,
+ * SAC_PROFILE_PARAMS); it is not the reference's default stream. */
+int sacopt_encode_frames_selected(sacopt_ctx *ctx, int profile, int nframes, const sacopt_frame *frames,
+                                  const double *prof, int ncoef_loop, double *best, sacopt_residuals *out);
+
 /* ---- FrameCoder::UnpredictStereoFrame(profile, 0, 1, numsamples)   src/codec.cpp:216-235 ------ */
 /* Decoder-side cascade: Stereo{Fast,Normal,High}::Unpredict + Update (src/profile.cpp:34-43,
  * 89-111, 161-186) with Remap::Unmap (src/coder/map.cpp:154-168) for channels coded mapped. One frame of one

@@ -1203,6 +1203,248 @@ static int final_pass_enqueue(sacopt_ctx *c, const ProfDesc &pd, const std::vect
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same pipeline enqueued in FOUR parts, for sacopt_encode_frames_selected: the frame is predicted with the parameters the
+// optimizer selects, and the optimizer fixes them in coefficient order (codec.cpp:389-406) -- the OLS stage's after round 0,
+// the lead stage's after round 2, ... -- so every part of the full-frame pass starts as soon as ITS parameters are final instead
+// of after the last round. Parts: 0 = OLS stage (c->sB), 1 = first LMS stage (sLead), 2 = second LMS stage (c->sB), 3 = the
+// stages behind it and the mixer (c->sD), chunk k of a part behind an event of chunk k of the part before. Same chunk edges,
+// job contents and kernels as final_pass_enqueue: identical results.
+struct FinalPipe {
+  sacopt_ctx *c = nullptr;
+  const ProfDesc *pd = nullptr;
+  const std::vector<DevFrame> *fr = nullptr;
+  std::vector<Chain> *chains = nullptr;
+  std::vector<int> edges;
+  int nchunk = 0, nch = 0;
+  std::vector<LpcJob> lpc;
+  std::vector<std::vector<double *>> lms_state;
+  std::vector<double *> mix_state;
+  std::vector<hipEvent_t> ev_lpc, ev_l0, ev_l1;
+  hipStream_t sLead = nullptr;
+  hipEvent_t staged = nullptr, done = nullptr;
+  bool queued[4] = {false, false, false, false};
+
+  int chunk_end(int k, int n) const { return n < edges[k + 1] ? n : edges[k + 1]; }
+  // the last coefficient (among the first ncoef_loop, the ones the optimizer decides) that part g reads
+  int needs(int g, int ncoef_loop) const {
+    int m = -1;
+    auto use = [&](int ci) { if (ci < ncoef_loop && ci > m) m = ci; };
+    use(0);
+    if (g >= 1) { use(pd->lms[0].c1); use(pd->lms[0].c2); }
+    if (g >= 2 && pd->nlms > 1) { use(pd->lms[1].c1); use(pd->lms[1].c2); }
+    if (g >= 3) { for (int q = 2; q < pd->nlms; q++) { use(pd->lms[q].c1); use(pd->lms[q].c2); } use(pd->cmix); }
+    return m;
+  }
+  int prepare(sacopt_ctx *ctx, const ProfDesc &p, const std::vector<DevFrame> &f, std::vector<Chain> &ch, hipEvent_t staged_ev) {
+    c = ctx; pd = &p; fr = &f; chains = &ch; staged = staged_ev;
+    const int nstage = p.nlms + 2, last = p.nlms + 1;
+    nch = (int)ch.size();
+    int max_n = 0;
+    for (Chain &x : ch) {
+      const int n = f[x.frame].n;
+      max_n = n > max_n ? n : max_n;
+      for (int s = 0; s < nstage; s++) {
+        StageBuf b;
+        if (s != last) {
+          for (int k = 0; k < 2; k++) {
+            b.p[k] = arena_alloc<double>(c, n);
+            b.xn[k] = arena_alloc<double>(c, n);
+            if (!b.p[k] || !b.xn[k]) { c->err = "device arena exhausted"; return 1; }
+          }
+        } else {
+          for (int k = 0; k < 2; k++) {
+            b.e[k] = arena_alloc<int32_t>(c, n);
+            b.u[k] = arena_alloc<int32_t>(c, n);
+            if (!b.e[k] || !b.u[k]) { c->err = "device arena exhausted"; return 1; }
+          }
+          b.umax = arena_alloc<int32_t>(c, 2);
+          if (!b.umax) { c->err = "device arena exhausted"; return 1; }
+        }
+        x.sb[s] = b;
+      }
+    }
+    edges = {0};  // (as final_pass_enqueue)
+    {
+      int t = 0;
+      if (max_n > 4 * PIPE_CHUNK) { t = 2 * LMS_CHUNK; edges.push_back(t); }
+      while (max_n - t > PIPE_CHUNK + PIPE_CHUNK / 2) { t += PIPE_CHUNK; edges.push_back(t); }
+      while (max_n - t > 2 * LMS_CHUNK) {
+        const int rem = max_n - t;
+        t += ((rem / 2 + LMS_CHUNK - 1) / LMS_CHUNK) * LMS_CHUNK;
+        edges.push_back(t);
+      }
+      if (t < max_n || edges.size() == 1) edges.push_back(max_n);
+    }
+    nchunk = (int)edges.size() - 1;
+    lpc.resize(nch);
+    for (int i = 0; i < nch; i++) {
+      const Chain &x = ch[i];
+      const DevFrame &df = f[x.frame];
+      LpcJob &j = lpc[i];
+      memset(&j, 0, sizeof(j));
+      for (int k = 0; k < 2; k++) { j.s[k] = df.s[k] + df.from; j.p[k] = x.sb[0].p[k]; j.x1[k] = x.sb[0].xn[k]; }
+      j.n = df.n;
+      if (lpc_scratch_alloc(c, p, j)) return 1;
+      for (int k = 0; k < 2; k++) {
+        j.cstate[k] = arena_alloc<double>(c, p.ols_n * (p.ols_n + 1) / 2 + p.ols_n);
+        j.estate[k] = arena_alloc<double>(c, p.ols_n);
+        if (!j.cstate[k] || !j.estate[k]) { c->err = "device arena exhausted"; return 1; }
+      }
+    }
+    lms_state.assign(p.nlms, std::vector<double *>(nch, nullptr));
+    mix_state.assign(nch, nullptr);
+    for (int i = 0; i < nch; i++) {
+      for (int q = 0; q < p.nlms; q++) {
+        lms_state[q][i] = arena_alloc<double>(c, sacopt_lms_state_doubles(p.lms[q].S, p.lms[q].D));
+        if (!lms_state[q][i]) { c->err = "device arena exhausted"; return 1; }
+      }
+      mix_state[i] = arena_alloc<double>(c, 2 * MIX_STATE);
+      if (!mix_state[i]) { c->err = "device arena exhausted"; return 1; }
+    }
+    ev_lpc.assign(nchunk, nullptr); ev_l0.assign(nchunk, nullptr); ev_l1.assign(nchunk, nullptr);
+    const int lead_wgs = nch * (sacopt_lms_variant(p.lms[0].S, p.lms[0].D, nch, c->bits, L1C_FRAMES) ? 2 : 1);
+    sLead = (c->sAall && lead_wgs > 32) ? c->sAall : c->sA;
+    return 0;
+  }
+  // job table of LMS stage q, chunk k (the chains still running in that chunk)
+  void lms_jobs(int q, int k, std::vector<LmsJob> &jobs, long long *units) const {
+    const int t0 = edges[k];
+    for (int i = 0; i < nch; i++) {
+      const Chain &x = (*chains)[i];
+      const int n = (*fr)[x.frame].n;
+      if (t0 >= n) continue;
+      LmsJob j;
+      for (int h = 0; h < 2; h++) { j.x[h] = x.sb[q].xn[h]; j.p[h] = x.sb[q + 1].p[h]; j.xn[h] = x.sb[q + 1].xn[h]; }
+      j.mu1 = x.coefs[pd->lms[q].c1];
+      j.mu2 = x.coefs[pd->lms[q].c2];
+      j.t0 = t0;
+      j.n = chunk_end(k, n) - t0;
+      j.state = lms_state[q][i];
+      jobs.push_back(j);
+      if (units) *units += j.n;
+    }
+  }
+  // Enqueue part g with the coefficients the chains hold NOW. Parts must be enqueued in order.
+  int enqueue(int g) {
+    if (queued[g]) return 0;
+    queued[g] = true;
+    const int last = pd->nlms + 1;
+    hipStream_t fs = c->sD ? c->sD : c->sB;
+    hipStream_t st = g == 0 ? c->sB : (g == 1 ? sLead : (g == 2 ? c->sB : fs));
+    Stager stg;
+    std::vector<size_t> off;  // per chunk (and stage, part 3) in launch order
+    std::vector<int> cnt;
+    std::vector<long long> units(nchunk, 0);
+    std::vector<int> len_lpc(nchunk, 0);
+    for (int k = 0; k < nchunk; k++) {
+      const int t0 = edges[k];
+      if (g == 0) {
+        std::vector<LpcJob> jobs;
+        for (int i = 0; i < nch; i++) {
+          const int n = (*fr)[(*chains)[i].frame].n;
+          if (t0 >= n) continue;
+          LpcJob j = lpc[i];
+          j.alpha = (*chains)[i].coefs[0];
+          j.t0 = t0;
+          j.n = chunk_end(k, n);
+          j.nsnap = j.n / 8;
+          len_lpc[k] = (j.n - t0 > len_lpc[k]) ? j.n - t0 : len_lpc[k];
+          jobs.push_back(j);
+        }
+        cnt.push_back((int)jobs.size());
+        off.push_back(stg.add(jobs.data(), jobs.size() * sizeof(LpcJob)));
+      } else if (g == 1 || g == 2) {
+        std::vector<LmsJob> jobs;
+        lms_jobs(g - 1, k, jobs, g == 1 ? &units[k] : nullptr);
+        cnt.push_back((int)jobs.size());
+        off.push_back(stg.add(jobs.data(), jobs.size() * sizeof(LmsJob)));
+      } else {
+        for (int q = 2; q < pd->nlms; q++) {
+          std::vector<LmsJob> jobs;
+          lms_jobs(q, k, jobs, nullptr);
+          cnt.push_back((int)jobs.size());
+          off.push_back(stg.add(jobs.data(), jobs.size() * sizeof(LmsJob)));
+        }
+        std::vector<MixJob> jobs;
+        for (int i = 0; i < nch; i++) {
+          const Chain &x = (*chains)[i];
+          const DevFrame &f = (*fr)[x.frame];
+          if (t0 >= f.n && !(k == 0 && f.n == 0)) continue;
+          MixJob j;
+          memset(&j, 0, sizeof(j));
+          for (int h = 0; h < 2; h++) {
+            j.s[h] = f.s[h] + f.from;
+            j.p0[h] = x.sb[0].p[h];
+            j.x1[h] = x.sb[0].xn[h];
+            for (int q = 0; q < pd->nlms; q++) j.pk[q][h] = x.sb[q + 1].p[h];
+            j.e[h] = x.sb[last].e[h];
+            j.u[h] = x.sb[last].u[h];
+          }
+          j.umax = x.sb[last].umax;
+          j.alpha = x.coefs[pd->cmix];
+          j.t0 = t0;
+          j.n = chunk_end(k, f.n) - t0;
+          j.state = mix_state[i];
+          jobs.push_back(j);
+        }
+        cnt.push_back((int)jobs.size());
+        off.push_back(stg.add(jobs.data(), jobs.size() * sizeof(MixJob)));
+      }
+    }
+    char *dev = arena_alloc<char>(c, stg.host.size() + 256);
+    if (!dev) { c->err = "device arena exhausted"; return 1; }
+    if (g == 0 || g == 1) HIPCK(c, hipStreamWaitEvent(st, staged, 0));  // the frames are on the device behind this
+    if (upload_bytes(c, dev, stg.host.data(), stg.host.size(), st)) return 1;
+    size_t idx = 0;
+    for (int k = 0; k < nchunk; k++) {
+      if (g == 0) {
+        if (sacopt_launch_lpc3(reinterpret_cast<LpcJob *>(dev + off[idx]), cnt[idx], len_lpc[k], pd->ols_n, st)) { c->err = "LPC3 launch failed"; return 1; }
+        idx++;
+        TAKE_EVENT(c, ev_lpc[k], false);
+        HIPCK(c, hipEventRecord(ev_lpc[k], st));
+      } else if (g == 1) {
+        HIPCK(c, hipStreamWaitEvent(st, ev_lpc[k], 0));
+        hipEvent_t a = nullptr, b = nullptr;
+        const bool dominant = pd->lms[0].S != 1280 || sacopt_lms_variant(pd->lms[0].S, pd->lms[0].D, cnt[idx], c->bits, L1C_FRAMES) == c->timed_variant;
+        if (dominant) {
+          TAKE_EVENT(c, a, true);
+          TAKE_EVENT(c, b, true);
+          HIPCK(c, hipEventRecord(a, st));
+        }
+        if (sacopt_launch_lms(pd->lms[0].S, pd->lms[0].D, reinterpret_cast<LmsJob *>(dev + off[idx]), cnt[idx], c->d_tab, c->bits, st, L1C_FRAMES, 0, 0)) { c->err = "k_lms launch failed"; return 1; }
+        idx++;
+        if (dominant) {
+          HIPCK(c, hipEventRecord(b, st));
+          c->lms_ev.push_back({a, b});
+          c->lms_units += units[k];
+        }
+        TAKE_EVENT(c, ev_l0[k], false);
+        HIPCK(c, hipEventRecord(ev_l0[k], st));
+      } else if (g == 2) {
+        HIPCK(c, hipStreamWaitEvent(st, ev_l0[k], 0));
+        if (sacopt_launch_lms(pd->lms[1].S, pd->lms[1].D, reinterpret_cast<LmsJob *>(dev + off[idx]), cnt[idx], c->d_tab, c->bits, st, L1C_FRAMES, 0, 0)) { c->err = "k_lms launch failed"; return 1; }
+        idx++;
+        TAKE_EVENT(c, ev_l1[k], false);
+        HIPCK(c, hipEventRecord(ev_l1[k], st));
+      } else {
+        HIPCK(c, hipStreamWaitEvent(st, ev_l1[k], 0));
+        for (int q = 2; q < pd->nlms; q++) {
+          if (sacopt_launch_lms(pd->lms[q].S, pd->lms[q].D, reinterpret_cast<LmsJob *>(dev + off[idx]), cnt[idx], c->d_tab, c->bits, st, L1C_FRAMES, 0, 0)) { c->err = "k_lms launch failed"; return 1; }
+          idx++;
+        }
+        if (sacopt_launch_mix(pd->nlms, reinterpret_cast<MixJob *>(dev + off[idx]), cnt[idx], st, 0, 0)) { c->err = "k_mix launch failed"; return 1; }
+        idx++;
+      }
+    }
+    if (g == 3) {
+      TAKE_EVENT(c, done, false);
+      HIPCK(c, hipEventRecord(done, st));
+    }
+    return 0;
+  }
+};
+
 // Full-frame (or any window) pass for all chains; long windows go through the pipeline.
 static bool final_pass_pipelined(const ProfDesc &pd, const std::vector<DevFrame> &fr, const std::vector<Chain> &chains) {
   int max_n = 0;
@@ -1575,7 +1817,8 @@ static size_t optimize_bytes(const ProfDesc &pd, int ncoef_loop, const std::vect
 // `after_first` (optional) runs once, right after the first round's kernels are enqueued and before the host waits for them.
 static int optimize_core(sacopt_ctx *c, const ProfDesc &pd, const std::vector<DevFrame> &fr, const double *prof, int ncoef_loop,
                          const std::vector<std::vector<double>> &grid, double *best, double *trace, int max_rows, int32_t *rows_out,
-                         const std::function<int()> &after_first = nullptr) {
+                         const std::function<int()> &after_first = nullptr,
+                         const std::function<int(int, const std::vector<std::vector<double>> &)> &after_round = nullptr) {
   const int nframes = (int)fr.size();
   std::vector<double> st(nframes, 0.);  // one CostGolomb instance per Optimize call (codec.cpp:364)
   double *d_state;
@@ -1631,6 +1874,7 @@ static int optimize_core(sacopt_ctx *c, const ProfDesc &pd, const std::vector<De
       cur[f][i] = best_x;  // later coefficients see earlier winners (codec.cpp:406)
     }
     base_done = true;
+    if (after_round && nc && after_round(i, cur)) return 1;  // coefficients 0..i are final from here on
   }
   for (int f = 0; f < nframes; f++) {
     memcpy(best + (size_t)f * pd.ncoef, cur[f].data(), 8 * pd.ncoef);
@@ -1745,6 +1989,79 @@ extern "C" int sacopt_encode_frames(sacopt_ctx *c, int profile, int nframes, con
     if (optimize_core(c, pd, win, prof, ncoef_loop, grid, best, nullptr, 0, nullptr,
                       opt_first ? std::function<int()>(enqueue_final) : std::function<int()>())) return 1;
     if (opt_first && !ran && run_final_pass(c, pd, fr, chains, &done, staged)) return 1;  // no round ran (empty grids)
+  }
+  if (done) HIPCK(c, hipStreamWaitEvent(c->st, done, 0));
+  return emit_outputs(c, pd, fr, chains, out);
+}
+
+// SURVEY 8f.2 as ONE call: Optimize(optprofile), then PredictStereoFrame(optprofile, 0, 1, 0, numsamples) -- the frame is coded
+// with the selected parameters, so the full-frame pass depends on the optimizer. It still does not have to wait for the last
+// round: the parts of the pass start as soon as their parameters are final (FinalPipe).
+extern "C" int sacopt_encode_frames_selected(sacopt_ctx *c, int profile, int nframes, const sacopt_frame *frames, const double *prof_in,
+                                             int ncoef_loop, double *best, sacopt_residuals *out) {
+  if (!c) return 1;
+  if (begin_call(c)) return 1;
+  ProfDesc pd;
+  if (!get_prof(profile, &pd)) { c->err = "unknown profile"; return 1; }
+  if (nframes < 0 || (nframes && (!frames || !out || !best))) { c->err = "bad arguments"; return 1; }
+  if (ncoef_loop <= 0 || ncoef_loop > pd.ncoef) { c->err = "ncoef_loop must be 1..the profile's coefficient count (the reference would index past coefs[], codec.cpp:389)"; return 1; }
+  if (!nframes) return 0;
+  if (check_frames(c, nframes, frames, nullptr, nullptr)) return 1;
+  double prof[3 * SACOPT_MAX_COEFS];
+  sacopt_base_profile(profile, prof);
+  if (prof_in) memcpy(prof, prof_in, sizeof(double) * 3 * pd.ncoef);
+  c->timed_variant = sacopt_lms_variant(1280, 640, nframes, c->bits, L1C_FRAMES);
+  std::vector<std::vector<double>> grid;
+  size_t total_cand = 0;
+  if (build_grid(c, prof, ncoef_loop, grid, &total_cand)) return 1;
+  size_t need = 1 << 20;
+  for (int f = 0; f < nframes; f++) {
+    const int ns = frames[f].numsamples;
+    need += chain_bytes(pd, ns) + 2 * (((size_t)ns * 4 + 255) & ~(size_t)255) + 4096 + lpc_scratch_bytes(pd, ns) + sizeof(LpcJob) + 256 + pipe_bytes(ns) +
+            ((out[f].map0 || out[f].map1) ? map_bytes(ns) : 0);
+    need += optimize_bytes(pd, ncoef_loop, grid, total_cand, ns / 8);
+  }
+  if (c->cost_fn == SACOPT_COST_BITPLANE) {
+    int mxn = 0;
+    for (int f = 0; f < nframes; f++) mxn = frames[f].numsamples / 8 > mxn ? frames[f].numsamples / 8 : mxn;
+    need += (size_t)(ncoef_loop + 1) * bitplane_cost_bytes(2 * (size_t)nframes * 13, mxn, 32);
+  }
+  if (arena_reserve(c, need)) return 1;
+  const bool use_split = c->split[0] && nframes <= 16 && pd.nlms == 4;
+  StreamSetGuard set_guard(c, use_split ? c->split : (nframes > BIG_FRAMES ? c->big : nullptr));
+  HIPCK(c, hipEventRecord(c->ev0, c->st));
+  std::vector<DevFrame> fr;
+  if (stage_frames(c, nframes, frames, nullptr, nullptr, fr)) return 1;
+  std::vector<Chain> chains(nframes);
+  for (int f = 0; f < nframes; f++) {
+    chains[f].frame = f;
+    for (int i = 0; i < pd.ncoef; i++) chains[f].coefs[i] = prof[3 * i + 2];
+  }
+  std::vector<DevFrame> win = fr;
+  for (DevFrame &w : win) { w.n = w.numsamples / 8; w.from = (w.numsamples - w.n) / 2; }
+  hipEvent_t done = nullptr;
+  if (!final_pass_pipelined(pd, fr, chains)) {  // short frames / the fast profile: nothing to overlap
+    if (optimize_core(c, pd, win, prof, ncoef_loop, grid, best, nullptr, 0, nullptr)) return 1;
+    for (int f = 0; f < nframes; f++) memcpy(chains[f].coefs, best + (size_t)f * pd.ncoef, 8 * pd.ncoef);
+    if (run_final_pass(c, pd, fr, chains, &done)) return 1;
+  } else {
+    hipEvent_t staged;
+    TAKE_EVENT(c, staged, false);
+    HIPCK(c, hipEventRecord(staged, c->st));
+    FinalPipe fp;
+    if (fp.prepare(c, pd, fr, chains, staged)) return 1;
+    auto after_round = [&](int i, const std::vector<std::vector<double>> &cur) -> int {
+      for (int g = 0; g < 4; g++)
+        if (!fp.queued[g] && fp.needs(g, ncoef_loop) <= i) {
+          for (int f = 0; f < nframes; f++) memcpy(chains[f].coefs, cur[f].data(), 8 * pd.ncoef);
+          if (fp.enqueue(g)) return 1;
+        } else if (!fp.queued[g]) break;  // in order
+      return 0;
+    };
+    if (optimize_core(c, pd, win, prof, ncoef_loop, grid, best, nullptr, 0, nullptr, nullptr, after_round)) return 1;
+    for (int f = 0; f < nframes; f++) memcpy(chains[f].coefs, best + (size_t)f * pd.ncoef, 8 * pd.ncoef);
+    for (int g = 0; g < 4; g++) if (fp.enqueue(g)) return 1;  // whatever no round released (rounds without candidates)
+    done = fp.done;
   }
   if (done) HIPCK(c, hipStreamWaitEvent(c->st, done, 0));
   return emit_outputs(c, pd, fr, chains, out);

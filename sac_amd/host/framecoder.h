@@ -95,7 +95,8 @@ class FrameCoder {
     }
   }
 
-  // Optimize, then PredictStereoFrame(optprofile, 0, 1, 0, numsamples): two library calls, the second needs the first's result
+  // Optimize, then PredictStereoFrame(optprofile, 0, 1, 0, numsamples): one library call (the parts of the full-frame pass start as
+  // soon as the optimizer has fixed their parameters)
   static void PredictBatchApply(sacopt_ctx *ctx, FrameCoder *const *fc, int nframes) {
     FrameCoder &f0 = *fc[0];
     const int ncoef = (int)f0.baseprofile.coefs.size();
@@ -112,8 +113,7 @@ class FrameCoder {
       out[b].s2u0 = f.s2u_error[0].data(); out[b].s2u1 = f.s2u_error[1].data();
       out[b].map0 = f.s2u_error_map[0].data(); out[b].map1 = f.s2u_error_map[1].data();
     }
-    check_on(ctx, sacopt_optimize_frames(ctx, f0.baseprofile.type, nframes, fr.data(), prof.data(), ncoef, best.data(), nullptr, 0, nullptr));
-    check_on(ctx, sacopt_predict_stereo_frames(ctx, f0.baseprofile.type, nframes, fr.data(), nullptr, nullptr, best.data(), out.data()));
+    check_on(ctx, sacopt_encode_frames_selected(ctx, f0.baseprofile.type, nframes, fr.data(), prof.data(), ncoef, best.data(), out.data()));
     for (int b = 0; b < nframes; b++) {
       FrameCoder &f = *fc[b];
       f.maxbpn[0] = out[b].maxbpn[0]; f.maxbpn[1] = out[b].maxbpn[1];

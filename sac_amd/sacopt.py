@@ -58,6 +58,7 @@ def lib():
         L.sacopt_optimize_frames.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                              C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.sacopt_encode_frames.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.sacopt_encode_frames_selected.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.sacopt_unpredict_stereo_frames.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.sacopt_cost_golomb.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.sacopt_coded_sizes.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -76,7 +77,7 @@ def lib():
 
 
 EXPORTS = ["sacopt_create", "sacopt_destroy", "sacopt_last_error", "sacopt_probe_rsqrt", "sacopt_base_profile",
-           "sacopt_predict_stereo_frames", "sacopt_set_cost_function", "sacopt_get_costs", "sacopt_recost_last", "sacopt_optimize_frames", "sacopt_encode_frames", "sacopt_unpredict_stereo_frames", "sacopt_cost_golomb", "sacopt_cost_golomb_noalloc", "sacopt_coded_sizes",
+           "sacopt_predict_stereo_frames", "sacopt_set_cost_function", "sacopt_get_costs", "sacopt_recost_last", "sacopt_optimize_frames", "sacopt_encode_frames", "sacopt_encode_frames_selected", "sacopt_unpredict_stereo_frames", "sacopt_cost_golomb", "sacopt_cost_golomb_noalloc", "sacopt_coded_sizes",
            "sacopt_cost_meanrms", "sacopt_lms_pair", "sacopt_lpc3_pair", "sacopt_rls_run", "sacopt_chol_solve", "sacopt_serial_sum",
            "sacopt_cascade_trace", "sacopt_last_timing"]
 
@@ -276,8 +277,9 @@ class Context:
                                               max_rows, _p(rows)))
         return best, [trace[f, :min(rows[f], max_rows)].copy() for f in range(nf)], rows
 
-    def encode(self, profile, frames, prof=None, ncoef_loop=None, device_out=None, maps=False):
-        """FrameCoder::Predict with Optimize enabled: returns (best[nframes,ncoef], residual dicts)."""
+    def encode(self, profile, frames, prof=None, ncoef_loop=None, device_out=None, maps=False, selected=False):
+        """FrameCoder::Predict with Optimize enabled: returns (best[nframes,ncoef], residual dicts). selected: the residuals are
+        those of PredictStereoFrame with the SELECTED parameters (sacopt_encode_frames_selected)."""
         nf = len(frames)
         arr, keep = self._frames(frames)
         nc = NCOEF[profile]
@@ -289,7 +291,8 @@ class Context:
         outs = []
         for i in range(nf):
             outs.append(self._residuals(res, i, arr[i].numsamples, device_out, maps))
-        self._ck(lib().sacopt_encode_frames(self._h, profile, nf, arr, _p(pf), ncoef_loop, _p(best), res))
+        fn = lib().sacopt_encode_frames_selected if selected else lib().sacopt_encode_frames
+        self._ck(fn(self._h, profile, nf, arr, _p(pf), ncoef_loop, _p(best), res))
         for i in range(nf):
             outs[i]["maxbpn"] = np.array(list(res[i].maxbpn), np.int32)
         return best, outs

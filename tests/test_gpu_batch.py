@@ -142,3 +142,34 @@ def test_unmasked_stream_fallback_vs_oracle(rsqrt_table, oracle):
             assert np.array_equal(got[f]["e0"], ref["e0"]) and np.array_equal(got[f]["e1"], ref["e1"]), f
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("prof,count", [(2, 5), (1, 4), (0, 3)])
+def test_encode_frames_selected_vs_two_calls(rsqrt_table, oracle, prof, count):
+    # sacopt_encode_frames_selected (SURVEY 8f.2 in one call: the parts of the full-frame pass are released as the optimizer fixes
+    # their parameters) against Optimize + PredictStereoFrame(selected parameters) as two calls, and one frame against the oracle
+    frames = _ragged_frames(8 + count, 7)[:count] + [stereo_clip(7100, 3000)]   # pipelined frames and one short frame
+    with sacopt.Context(0, *rsqrt_table) as c:
+        best1, outs1 = c.encode(prof, frames, maps=True, selected=True)
+        best2, _, _ = c.optimize(prof, frames, ncoef_loop=sacopt.NCOEF[prof])
+        outs2 = c.predict(prof, frames, coefs=best2, maps=True)
+        assert same_bits(best1, best2)
+        for f in range(len(frames)):
+            for k in KEYS:
+                assert np.array_equal(outs1[f][k], outs2[f][k]), (f, k)
+        # fewer coefficients than the profile has: the rest stay at their base values
+        part = min(2, sacopt.NCOEF[prof])
+        b3, o3 = c.encode(prof, frames[:2], maps=True, selected=True, ncoef_loop=part)
+        b4, _, _ = c.optimize(prof, frames[:2], ncoef_loop=part)
+        assert same_bits(b3, b4)
+        o4 = c.predict(prof, frames[:2], coefs=b4, maps=True)
+        for f in range(2):
+            for k in KEYS:
+                assert np.array_equal(o3[f][k], o4[f][k]), (f, k)
+    L, R = frames[1]
+    nc = sacopt.NCOEF[prof]
+    ob, _ = oracle.optimize(prof, L, R, ncoef_loop=nc)
+    assert same_bits(best1[1], ob[:nc])
+    ref = oracle.predict(prof, L, R, coefs=ob[:nc], maps=True)
+    for k in KEYS:
+        assert np.array_equal(outs1[1][k], ref[k]), k
