@@ -5,7 +5,7 @@ import numpy as np, torch
 torch.cuda.init()
 from sac_amd import sacopt
 from sac_amd.synth import stereo_clip
-FRAME, NF = 176400, 15
+FRAME, NF = 176400, int(sys.argv[1]) if len(sys.argv) > 1 else 15
 L, R = stereo_clip(1000, NF * FRAME)
 dL = torch.from_numpy(L).cuda(); dR = torch.from_numpy(R).cuda()
 frames = [(dL.data_ptr() + 4 * f * FRAME, dR.data_ptr() + 4 * f * FRAME, FRAME) for f in range(NF)]

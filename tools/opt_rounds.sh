@@ -2,7 +2,7 @@
 # per-round spans of the optimizer alone (15 frames): rocprofv3 kernel trace of tools/opt_only.py -> tools/rounds_summary.py
 cd ${GRAFT_REPO_ROOT:-.}; export TMPDIR=/tmp
 O=gpurun_out/optr; mkdir -p $O
-timeout -s KILL 300 rocprofv3 --kernel-trace -d $O/kt -o kt -- python3 tools/opt_only.py > $O/run.log 2>&1 || exit 1
+timeout -s KILL 300 rocprofv3 --kernel-trace -d $O/kt -o kt -- python3 tools/opt_only.py ${1:-15} > $O/run.log 2>&1 || exit 1
 python3 tools/rounds_summary.py $O/kt/kt_results.db
 python3 - <<'PY'
 import sqlite3
