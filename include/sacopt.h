@@ -168,7 +168,9 @@ int sacopt_cost_meanrms(sacopt_ctx *ctx, const int32_t *buf, int n, double *cost
  * planes + 1 (framestats[ch].maxbpn, src/codec.cpp:207-208), exactly. One coder per GPU lane, so the call pays off for many
  * buffers at once (candidates x channels x frames); the bytes themselves stay the host coder's job. s2u: host array of nbuf
  * host-or-device pointers; n, maxbpn, sizes: host arrays. The coder's logistic tables (src/model/domain.h:12-23) are
- * tabulated with the libm of the host that created the context, as the reference's static initialiser does. */
+ * tabulated with the libm of the host that created the context, as the reference's static initialiser does.
+ * maxbpn[b] in 0..30. A value may have bits above plane maxbpn[b] (s2u of a residual beyond 2^30 wraps negative and the
+ * reference's signed maximum skips it): as in the reference, planes maxbpn[b]..0 of its two's-complement bits are coded. */
 int sacopt_coded_sizes(sacopt_ctx *ctx, int nbuf, const int32_t *const *s2u, const int32_t *n, const int32_t *maxbpn, int32_t *sizes);
 
 /* ---- CostGolomb::Calc without any allocation ------------------------------------------------------------------

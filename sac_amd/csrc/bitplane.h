@@ -414,9 +414,13 @@ __global__ __launch_bounds__(BPP_NT) void k_bppipe(const BpJob *__restrict__ job
         for (int q = 0; q < 9; q++) a[q] = tile[cod][lane + q];  // a[4] = abuf[s]
         __builtin_amdgcn_wave_barrier();
         const int s = s0 + lane;
-        auto hb = [](int x) -> int { return x ? 31 - __clz(x) : -1; };
         // msb[] of a sample (vle.cpp:132: the plane of its first set bit, once that plane's decision has been coded; 0 before --
-        // and for good when that plane is 0): `before` its decision in this plane, and `after`
+        // and for good when that plane is 0): `before` its decision in this plane, and `after`. "First set bit" = of the CODED
+        // planes: a value may have bits above maxbpn (s2u of a residual beyond 2^30 wraps negative and MaxBPN's signed maximum
+        // skips it, codec.cpp:178-211); the reference never looks at those planes for msb[], but its context comparisons below
+        // shift the whole signed value.
+        const int vmask = (int)((2u << mbp) - 1u);
+        auto hb = [&](int x) -> int { x &= vmask; return x ? 31 - __clz(x) : -1; };
         auto before = [&](int x) -> int { const int h = hb(x); return h > bpn ? h : 0; };
         auto after = [&](int x) -> int { const int h = hb(x); return h >= bpn ? h : 0; };
         const int mymsb = before(a[4]);

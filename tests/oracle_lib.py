@@ -292,5 +292,21 @@ def ref_decode_channels(ref, profile, n, ch0, ch1):
     return e0, e1, (used[0] if ch0[1] else None), (used[1] if ch1[1] else None)
 
 
+def out_of_plane_buffers():
+    """s2u buffers with bits ABOVE the coded planes: s2u of a residual beyond 2^30 wraps negative and MaxBPN's signed maximum
+    (codec.cpp:178-211) skips it -- a diverged filter does that (found by tools/fuzz_parity.py). The coder then codes planes
+    maxbpn..0 of the two's-complement bits, msb[] only ever sees the coded planes, the context comparisons shift the signed
+    value (vle.cpp:32-60). [(buffer, maxbpn)]"""
+    rs = np.random.RandomState(4)
+    n = 700
+    out = []
+    for mb, mk in ((8, lambda: rs.randint(0, 1 << 13, n)),
+                   (12, lambda: np.where(rs.rand(n) < 0.05, -rs.randint(1, 1 << 30, n), rs.randint(0, 1 << 13, n))),
+                   (28, lambda: np.where(rs.rand(n) < 0.02, rs.randint(-2 ** 31, 2 ** 31 - 1, n), rs.randint(0, 1 << 20, n)))):
+        for _ in range(2):
+            out.append((mk().astype(np.int32), mb))
+    return out
+
+
 def have_ref():
     return os.path.exists(_REF_SO)

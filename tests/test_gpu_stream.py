@@ -196,6 +196,8 @@ def test_coded_sizes_vs_restated_coder(oracle):
         bufs.append(rs.randint(0, 1 << (top + 1), nb).astype(np.int32)); mb.append(top)
     for nb in (63, 64, 65, 128, 129, 191):   # around the edges of k_bppipe's blocks of 64 decisions
         bufs.append(rs.randint(0, 1 << 9, nb).astype(np.int32)); mb.append(8)
+    for b, m in oracle_lib.out_of_plane_buffers():   # values with bits above the coded planes, negative ones included
+        bufs.append(b); mb.append(m)
     with sacopt.Context(0) as c:
         got = c.coded_sizes(bufs, mb)
     for i, (b, m) in enumerate(zip(bufs, mb)):

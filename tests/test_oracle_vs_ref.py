@@ -211,6 +211,24 @@ def test_bitplane_coder_bytes(pair):
     assert mapped_seen and plain_seen
 
 
+def test_bitplane_coder_values_beyond_the_planes(pair):
+    # the restated coder against the reference's Encode() where the buffer has bits above maxbpn (the mapped variant is fed
+    # the same buffer, so the plain one -- strictly smaller: no table in front -- is what the reference keeps)
+    import ctypes as C
+    import oracle_lib
+    o, r = pair
+    bufs = oracle_lib.out_of_plane_buffers()
+    for k in range(0, len(bufs), 2):
+        (u0, mb), (u1, _) = bufs[k], bufs[k + 1]
+        z = np.zeros(len(u0), np.int32)
+        want = oracle_lib.ref_encode_channels(r, 1, z, z, dict(u0=u0, u1=u1, m0=u0, m1=u1, maxbpn=np.array([mb] * 4, np.int32)))
+        for ch, u in enumerate((u0, u1)):
+            cap = 16 * len(u) + 70000
+            out = np.zeros(cap, np.uint8)
+            n = o.lib.oracle_encode_mono_normal(u.ctypes.data_as(C.c_void_p), C.c_int(len(u)), C.c_int(mb), out.ctypes.data_as(C.c_void_p), C.c_int(cap))
+            assert not want[ch][1] and out[:n].tobytes() == want[ch][0], (k, ch, n, len(want[ch][0]))
+
+
 def test_optimize_with_cost_mean_rms(pair):
     # FrameCoder::Optimize's schedule driven with the reference's OTHER CostFunction, CostMeanRMS (codec.cpp:302-312)
     o, r = pair

@@ -1,0 +1,135 @@
+"""Randomised differential run of the library against the C restatement (oracle/), wider than tests/ and tools/soak.py: all four
+profiles, random coefficient vectors inside the profile's ranges, eight signal families (tonal clip, silence, DC, full-scale
+square, sparse alphabets that switch Remap on, white noise, very quiet noise, impulses), lengths on and around every block
+edge of the kernels (8, 32, 64, 256, 512, 2048, 4096, 7056, 16384) and random ones. Per round and profile:
+  predict   one call of all clips AND single-clip calls (both (1280,640) kernels)   == oracle: e, u, m, maxbpn
+  unpredict plain residuals, and mapped ones with the tables of Remap::Analyse      == oracle and == the input samples
+  optimize  a few short clips, random number of optimised coefficients                == oracle: winners and cost trace
+  coded sizes of the plain and mapped s2u buffers of every clip                       == oracle coder's byte counts
+usage: fuzz_parity.py [seed] [rounds] [clips per round]      (test infrastructure: it uses the oracle)"""
+import ctypes as C
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+import oracle_lib
+from sac_amd import sacopt
+from sac_amd.synth import stereo_clip
+
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+nclips = int(sys.argv[3]) if len(sys.argv) > 3 else 40
+rs = np.random.RandomState(seed)
+oracle_lib.build_oracle()
+orc = oracle_lib.Oracle()
+_t = np.load(os.path.join(ROOT, "tests", "golden", "rsqrt_table.npz"), allow_pickle=False)
+tab, bits = _t["tab"].astype(np.float32), int(_t["bits"])   # the fixture's rsqrtss table on both sides
+orc.set_rsqrt_table(tab, bits)
+
+EDGES = [1, 2, 7, 8, 9, 31, 32, 33, 63, 64, 65, 255, 256, 257, 511, 512, 513, 1023, 1025, 2047, 2048, 2049, 4095, 4096, 4097,
+         7055, 7056, 7057, 8192, 16383, 16384, 16385]
+
+
+def signal(kind, n):
+    s = int(rs.randint(1, 1 << 30))
+    if kind == 0:
+        return stereo_clip(s, n)
+    if kind == 1:
+        return np.zeros(n, np.int32), np.zeros(n, np.int32)
+    if kind == 2:
+        return np.full(n, int(rs.randint(-32768, 32768)), np.int32), np.full(n, int(rs.randint(-32768, 32768)), np.int32)
+    if kind == 3:   # full-scale square waves of different periods
+        p0, p1 = int(rs.randint(2, 200)), int(rs.randint(2, 200))
+        t = np.arange(n)
+        return np.where((t // p0) & 1, 32767, -32768).astype(np.int32), np.where((t // p1) & 1, -32768, 32767).astype(np.int32)
+    if kind == 4:   # sparse alphabet: Remap pays
+        L, R = stereo_clip(s, n)
+        q0, q1 = int(rs.randint(2, 40)), int(rs.randint(2, 40))
+        return ((L // q0) * q0).astype(np.int32), ((R // q1) * q1).astype(np.int32)
+    if kind == 5:
+        r = np.random.RandomState(s)
+        return r.randint(-32768, 32768, n).astype(np.int32), r.randint(-32768, 32768, n).astype(np.int32)
+    if kind == 6:
+        r = np.random.RandomState(s)
+        return r.randint(-3, 4, n).astype(np.int32), r.randint(-1, 2, n).astype(np.int32)
+    r = np.random.RandomState(s)   # impulses on silence
+    L = np.zeros(n, np.int32); R = np.zeros(n, np.int32)
+    k = max(1, n // 97)
+    L[r.randint(0, n, k)] = r.randint(-32768, 32768, k); R[r.randint(0, n, k)] = r.randint(-32768, 32768, k)
+    return L, R
+
+
+def s2u_inv(u):   # utils.h:62-66
+    return np.where(u & 1, ((u.astype(np.int64) + 1) >> 1), -(u.astype(np.int64) >> 1)).astype(np.int32)
+
+
+def coder_size(buf, maxbpn):
+    b = np.ascontiguousarray(buf, dtype=np.int32)
+    return orc.lib.oracle_encode_mono_normal(b.ctypes.data_as(C.c_void_p), C.c_int(len(b)), C.c_int(int(maxbpn)), None, C.c_int(0))
+
+
+bad = 0
+def check(ok, *what):
+    global bad
+    if not ok:
+        bad += 1
+        print("MISMATCH", *what, flush=True)
+
+
+KEYS = ("e0", "e1", "u0", "u1", "m0", "m1", "maxbpn")
+with sacopt.Context(0, tab, bits) as ctx:
+    for rnd in range(rounds):
+        for prof in (2, 1, 0, 3):
+            t = time.time()
+            base = orc.base_profile(prof)
+            lens = [int(rs.choice(EDGES)) if rs.rand() < 0.5 else int(rs.choice([rs.randint(1, 600), rs.randint(600, 5000), rs.randint(5000, 20000), rs.randint(20000, 45000)], p=[.3, .45, .2, .05]))
+                    for _ in range(nclips)]
+            kinds = [int(rs.randint(0, 8)) for _ in range(nclips)]
+            clips = [signal(k, n) for k, n in zip(kinds, lens)]
+            # one coefficient vector per clip: the profile's defaults or a random point of its ranges
+            coefs = np.array([[(v[2] if rs.rand() < 0.3 else v[0] + rs.rand() * (v[1] - v[0])) for v in base] for _ in range(nclips)])
+            allres = ctx.predict(prof, clips, coefs=coefs, maps=True)
+            refs = []
+            for i, (L, R) in enumerate(clips):
+                ref = orc.predict(prof, L, R, coefs=coefs[i], maps=True)
+                refs.append(ref)
+                for k in KEYS:
+                    check(np.array_equal(allres[i][k], ref[k]), "predict batch", prof, i, kinds[i], len(L), k)
+                if i % 4 == 0:
+                    one = ctx.predict(prof, [(L, R)], coefs=coefs[i:i + 1], maps=True)[0]
+                    for k in KEYS:
+                        check(np.array_equal(one[k], ref[k]), "predict single", prof, i, kinds[i], len(L), k)
+            # decoder: plain residuals of every clip in one call; mapped ones for the sparse clips
+            dec = ctx.unpredict(prof, [dict(e0=r["e0"], e1=r["e1"]) for r in refs], coefs=coefs)
+            for i, (L, R) in enumerate(clips):
+                # (the high profiles' encoder does not clamp but their decoder does: identical while the prediction stays in range)
+                o = orc.unpredict(prof, refs[i]["e0"], refs[i]["e1"], coefs=coefs[i])
+                check(np.array_equal(dec[i][0], o[0]) and np.array_equal(dec[i][1], o[1]), "unpredict vs oracle", prof, i, kinds[i], len(L))
+                check(np.array_equal(dec[i][0], L) and np.array_equal(dec[i][1], R), "unpredict round trip", prof, i, kinds[i], len(L))
+            if prof in (1, 2):
+                sp = [i for i in range(nclips) if kinds[i] in (3, 4, 7)][:6]
+                if sp:
+                    fr = [dict(e0=s2u_inv(refs[i]["m0"]), e1=s2u_inv(refs[i]["m1"]), used0=orc.remap_tables(clips[i][0]), used1=orc.remap_tables(clips[i][1])) for i in sp]
+                    dm = ctx.unpredict(prof, fr, coefs=coefs[sp])
+                    for j, i in enumerate(sp):
+                        check(np.array_equal(dm[j][0], clips[i][0]) and np.array_equal(dm[j][1], clips[i][1]), "mapped round trip", prof, i, kinds[i], lens[i])
+            # coded sizes of both residual forms
+            bufs, mb = [], []
+            for r in refs:
+                bufs += [r["u0"], r["u1"], r["m0"], r["m1"]]
+                mb += [int(r["maxbpn"][0]), int(r["maxbpn"][1]), int(r["maxbpn"][2]), int(r["maxbpn"][3])]
+            got = ctx.coded_sizes(bufs, mb)
+            for j in range(len(bufs)):
+                check(int(got[j]) == coder_size(bufs[j], mb[j]), "coded size", prof, j // 4, j % 4, len(bufs[j]), mb[j])
+            # optimizer: a few short clips in one call
+            if prof < 3:
+                pick = [i for i in range(nclips) if 64 <= lens[i] <= 6000][:4]
+                if pick:
+                    ncl = int(rs.randint(1, sacopt.NCOEF[prof] + 1))
+                    best, traces, _ = ctx.optimize(prof, [clips[i] for i in pick], ncoef_loop=ncl)
+                    for j, i in enumerate(pick):
+                        ob, ot = orc.optimize(prof, *clips[i], ncoef_loop=ncl)
+                        check(best[j].tobytes() == ob[:best.shape[1]].tobytes() and traces[j].tobytes() == ot.tobytes(), "optimize", prof, i, kinds[i], lens[i], ncl)
+            print(f"round {rnd} profile {prof}: {nclips} clips, {sum(lens)} samples, {time.time() - t:.1f} s, mismatches so far {bad}", flush=True)
+print("FUZZ", "FAILED" if bad else "ok")
+sys.exit(1 if bad else 0)
