@@ -563,7 +563,12 @@ static int remap_is_used(const remap_t *r, int val) { /* map.cpp:132-139 */
   if (val < 0) return r->usedl[-val];
   return 1;
 }
-static int32_t remap_map(const remap_t *r, int32_t pred, int32_t err) { /* map.cpp:141-152 */
+/* Remap::Map, map.cpp:141-152, line by line. `err = -err` and `pred + sgn * i` are signed overflow when a diverged filter's
+ * prediction is far outside the sample range (err == INT32_MIN; a walk that runs over the end of int32): undefined in the
+ * reference, "parity unpinned" there. This file is compiled with -fwrapv (oracle/Makefile), which is what the reference's
+ * build does in practice: -INT32_MIN stays negative (the loop does not run, 0 comes back), the walk continues at the other
+ * end of int32. */
+static int32_t remap_map_literal(const remap_t *r, int32_t pred, int32_t err) {
   int sgn = 1;
   if (err == 0) return 0;
   if (err < 0) { err = -err; sgn = -1; }
@@ -572,11 +577,38 @@ static int32_t remap_map(const remap_t *r, int32_t pred, int32_t err) { /* map.c
     if (remap_is_used(r, pred + (sgn * i))) merr++;
   return sgn * merr;
 }
+/* The same count without the idle steps: isUsed() is 0 outside [-RSCALE, RSCALE] (map.cpp:133-134), so only the i whose
+ * (wrapped) pred + sgn * i lies in the table are visited -- a residual of 3e8 is 3e8 loop steps in the literal form, a
+ * wrapped walk 2^31. Two runs of i: before the walk leaves int32, and after it has come back at the other end.
+ * tests/test_oracle_golden.py::test_remap_map_forms compares the two forms. */
+static int32_t remap_map(const remap_t *r, int32_t pred, int32_t err) {
+  if (err == 0 || err == INT32_MIN) return 0;
+  const int sgn = err < 0 ? -1 : 1;
+  const int64_t n = err < 0 ? -(int64_t)err : (int64_t)err, p = pred;
+  const int64_t nowrap = sgn > 0 ? (int64_t)INT32_MAX - p : p - (int64_t)INT32_MIN; /* steps before the walk leaves int32 */
+  int merr = 0;
+  for (int part = 0; part < 2; part++) {
+    const int64_t off = part ? ((int64_t)1 << 32) : 0; /* value visited at step i: p + sgn * i - sgn * off */
+    int64_t ia = sgn > 0 ? -RSCALE - p + off : p - RSCALE + off, ib = sgn > 0 ? RSCALE - p + off : p + RSCALE + off;
+    const int64_t lo = part ? nowrap + 1 : 1, hi = part ? n : (n < nowrap ? n : nowrap);
+    if (ia < lo) ia = lo;
+    if (ib > hi) ib = hi;
+    for (int64_t i = ia; i <= ib; i++)
+      if (remap_is_used(r, (int)(p + sgn * i - sgn * off))) merr++;
+  }
+  return sgn * merr;
+}
 
 void oracle_remap_map(const int32_t *src, int n, const int32_t *pred, const int32_t *err, int m, int32_t *out) {
   remap_t *r = (remap_t *)malloc(sizeof(remap_t));
   remap_analyse(r, src, n);
   for (int i = 0; i < m; i++) out[i] = remap_map(r, pred[i], err[i]);
+  free(r);
+}
+void oracle_remap_map_literal(const int32_t *src, int n, const int32_t *pred, const int32_t *err, int m, int32_t *out) {
+  remap_t *r = (remap_t *)malloc(sizeof(remap_t));
+  remap_analyse(r, src, n);
+  for (int i = 0; i < m; i++) out[i] = remap_map_literal(r, pred[i], err[i]);
   free(r);
 }
 

@@ -2098,10 +2098,11 @@ __global__ void __launch_bounds__(MAP_SCAN_NT) k_map_scan(const MapJob *jobs) { 
   for (int i = lo; i < hi; i++) { run += tab[i]; tab[i] = run; }
 }
 
-__device__ __forceinline__ int map_rank(const int32_t *tab, int v) {  // #used values <= v
+__device__ __forceinline__ int map_rank(const int32_t *tab, long long v) {  // #used values <= v
   if (v < -MAP_SCALE) return 0;
-  return tab[(v > MAP_SCALE ? MAP_SCALE : v) + MAP_SCALE];
+  return tab[(int)(v > MAP_SCALE ? MAP_SCALE : v) + MAP_SCALE];
 }
+__device__ __forceinline__ int map_used(const int32_t *tab, long long a, long long b) { return a <= b ? map_rank(tab, b) - map_rank(tab, a - 1) : 0; }  // #used values in [a, b]
 
 __global__ void k_map_apply(const MapJob *jobs) {  // Remap::Map + S2U + running max (codec.cpp:175-204)
   const MapJob job = jobs[blockIdx.y];
@@ -2109,9 +2110,20 @@ __global__ void k_map_apply(const MapJob *jobs) {  // Remap::Map + S2U + running
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < job.n; i += gridDim.x * blockDim.x) {
     const int err = job.e[i];
     const int pred = job.sw[i] - err;  // codec.cpp:175
+    // Map's loop visits pred + sgn * i for i = 1..|err| (map.cpp:141-152). A diverged filter's prediction can be anything in int32
+    // (cvt_i32_x86 gives INT32_MIN out of range) and err = val - pred wraps with it, so the walk may run over the end of int32
+    // and come back at the other: the reference's `pred + sgn * i` is signed overflow there (undefined; its build wraps, and so
+    // does the oracle's, compiled with -fwrapv). Counted as that walk: the part up to the end of int32, then the part from the
+    // other end. err == INT32_MIN: `err = -err` stays negative and the loop does not run.
+    constexpr long long IMAX = 2147483647ll, IMIN = -2147483648ll;
     int merr = 0;
-    if (err > 0) merr = map_rank(job.tab, pred + err) - map_rank(job.tab, pred);
-    else if (err < 0) merr = -(map_rank(job.tab, pred - 1) - map_rank(job.tab, pred + err - 1));
+    if (err > 0) {
+      const long long hi = (long long)pred + err;
+      merr = map_used(job.tab, (long long)pred + 1, hi < IMAX ? hi : IMAX) + (hi > IMAX ? map_used(job.tab, IMIN, hi - 4294967296ll) : 0);
+    } else if (err < 0 && err != (int)IMIN) {
+      const long long lo = (long long)pred + err;
+      merr = -(map_used(job.tab, lo > IMIN ? lo : IMIN, (long long)pred - 1) + (lo < IMIN ? map_used(job.tab, lo + 4294967296ll, IMAX) : 0));
+    }
     const int u = merr < 0 ? 2 * (-merr) : (merr > 0 ? 2 * merr - 1 : 0);  // MathUtils::S2U (utils.h:56-61)
     if (job.m) job.m[i] = u;
     mx = u > mx ? u : mx;

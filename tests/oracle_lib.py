@@ -189,6 +189,14 @@ class Oracle(_Lib):
     def cholesky_kat(self):
         return bool(self.lib.oracle_cholesky_kat())
 
+    def remap_map_literal(self, src, pred, err):
+        """Remap::Map as the loop of map.cpp:141-152, every step taken (slow for large |err|)."""
+        src = np.ascontiguousarray(src, dtype=np.int32)
+        pred = np.ascontiguousarray(pred, dtype=np.int32); err = np.ascontiguousarray(err, dtype=np.int32)
+        out = np.zeros(len(pred), np.int32)
+        self.lib.oracle_remap_map_literal(_ptr(src), C.c_int(len(src)), _ptr(pred), _ptr(err), C.c_int(len(pred)), _ptr(out))
+        return out
+
     def remap_tables(self, src):
         """Remap::Analyse of a frame as the decoder's tables: usedl[0..32768] then usedh[0..32768] (bytes)."""
         src = np.ascontiguousarray(src, dtype=np.int32)
@@ -306,6 +314,31 @@ def out_of_plane_buffers():
         for _ in range(2):
             out.append((mk().astype(np.int32), mb))
     return out
+
+
+def diverging_impulse_clip():
+    """(L, R, coefs) of a case tools/fuzz_parity.py found: sparse full-scale impulses on silence with these (in-range) high
+    profile coefficients drive the cascade's predictions out of int32 -- cvttsd2si gives INT32_MIN, err = val - pred wraps
+    (residuals of 3e8 .. 2^31), s2u wraps negative, and Remap::Map's walk runs over the end of int32. The reference's
+    behaviour is its build's wrapping arithmetic there; oracle/Makefile says -fwrapv."""
+    n = 1759
+    L = np.zeros(n, np.int32); R = np.zeros(n, np.int32)
+    L[[47, 49, 115, 234, 244, 376, 456, 503, 543, 716, 933, 949, 1055, 1069, 1277, 1407, 1651, 1730]] = [
+        -5941, 30226, 10683, -25412, 31270, 3464, -24881, -5348, -27855, 16359, -11687, -2417, -26635, -18838, -952, -15212, 18390, -11699]
+    R[[155, 266, 304, 333, 524, 849, 880, 944, 947, 1058, 1100, 1101, 1141, 1225, 1394, 1408, 1561, 1650]] = [
+        -13296, 6951, 23511, -18677, 20849, 12254, 20489, 15286, -4310, 32742, 21172, 5557, 25609, 13921, -22165, -30665, -23917, -21356]
+    coefs = np.array([0.9963248028931021, 1e-05, 5e-06, 0.0008946247490625482, 0.0003390631856487167, 0.0018940434635736038, 0.01,
+                      0.9936731708629059])
+    return L, R, coefs
+
+
+def map_wrap_cases():
+    """(src, pred, err) for Remap::Map where `-err` or `pred + sgn * i` leave int32 (and two ordinary ones)."""
+    rs = np.random.RandomState(2)
+    src = (rs.randint(-32768, 32768, 3000) // 7 * 7).astype(np.int32)
+    lo, hi = -2 ** 31, 2 ** 31 - 1
+    cases = [(lo, lo), (lo, lo + 5), (hi - 10, hi - 5000), (hi - 100, lo + 2100), (lo, 5), (hi, -7), (-40000, 90000), (300, -70000)]
+    return src, np.array([c[0] for c in cases], np.int32), np.array([c[1] for c in cases], np.int32)
 
 
 def have_ref():

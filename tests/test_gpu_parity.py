@@ -359,6 +359,25 @@ def test_degenerate_inputs_vs_oracle(ctx, oracle):
                 assert np.array_equal(o[k], ref[k]), (name, prof, k)
 
 
+def test_predict_diverged_filter_beyond_int32(ctx, oracle):
+    # predictions out of int32 (cvttsd2si -> INT32_MIN), residuals that wrap, s2u that wraps negative, Remap::Map walks that
+    # run over the end of int32: the arithmetic of the reference's build (tests/test_oracle_vs_ref.py pins the oracle there)
+    import oracle_lib
+    L, R, coefs = oracle_lib.diverging_impulse_clip()
+    ref = oracle.predict(2, L, R, coefs=coefs, maps=True)
+    assert ref["e0"].min() == -2 ** 31 and (ref["u0"] < 0).any()
+    got = ctx.predict(2, [(L, R)] * 2, coefs=np.stack([coefs, coefs]), maps=True)
+    for g in got:
+        for k in ("e0", "e1", "u0", "u1", "m0", "m1", "maxbpn"):
+            assert np.array_equal(g[k], ref[k]), k
+    # the coded size of such a buffer: planes maxbpn..0 of the two's-complement bits
+    import ctypes as C
+    sz = ctx.coded_sizes([ref["u0"], ref["u1"]], [int(ref["maxbpn"][0]), int(ref["maxbpn"][1])])
+    for b, m, s in zip((ref["u0"], ref["u1"]), ref["maxbpn"][:2], sz):
+        b = np.ascontiguousarray(b)
+        assert s == oracle.lib.oracle_encode_mono_normal(b.ctypes.data_as(C.c_void_p), C.c_int(len(b)), C.c_int(int(m)), None, C.c_int(0))
+
+
 def test_optimize_small_budget_vs_oracle(ctx, oracle):
     # BASELINE configs[1]: "small candidate budget" = coefficient 0 only (baseline + 10 GetCost calls)
     frames = [stereo_clip(80, 4096), stereo_clip(81, 3333)]

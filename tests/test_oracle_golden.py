@@ -126,3 +126,18 @@ def test_ols32_stage_matches_reference_class(oracle, golden):
     # the oracle-made rows of profile 3 are reproducible (they pin the GPU, not the oracle)
     d = oracle.predict(3, golden["pred_L"], golden["pred_R"], frm=0, n=4096)
     assert np.array_equal(d["e0"], c5["o32_e0"]) and np.array_equal(d["e1"], c5["o32_e1"])
+
+
+def test_remap_map_forms(oracle):
+    # the oracle's Remap::Map visits only the steps whose value can be in the table; the literal loop of map.cpp:141-152 takes
+    # every step. Same counts: ordinary predictions / residuals, and walks that leave int32 (a few seconds: 2^31 steps each)
+    import oracle_lib
+    rs = np.random.RandomState(1)
+    src = (rs.randint(-32768, 32768, 3000) // 7 * 7).astype(np.int32)
+    pred = rs.randint(-200000, 200000, 4000).astype(np.int32); err = rs.randint(-200000, 200000, 4000).astype(np.int32)
+    pred[:500] = rs.randint(-40000, 40000, 500); err[:500] = rs.randint(-300, 300, 500)
+    assert np.array_equal(oracle.remap_map(src, pred, err), oracle.remap_map_literal(src, pred, err))
+    src, pred, err = oracle_lib.map_wrap_cases()
+    got = oracle.remap_map(src, pred, err)
+    assert np.array_equal(got, oracle.remap_map_literal(src, pred, err))
+    assert got[0] == 0 and got[1] < 0 and got[2] > 0   # -INT32_MIN stays negative: no steps; the wrapped walks do count

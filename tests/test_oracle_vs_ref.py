@@ -229,6 +229,23 @@ def test_bitplane_coder_values_beyond_the_planes(pair):
             assert not want[ch][1] and out[:n].tobytes() == want[ch][0], (k, ch, n, len(want[ch][0]))
 
 
+def test_remap_map_beyond_int32(pair):
+    # Remap::Map where the reference's int32 arithmetic overflows (undefined; its build wraps): the restatement, compiled
+    # with -fwrapv, returns what the reference's compiled code returns. The diverging clip: whole PredictStereoFrame + Map.
+    import oracle_lib
+    o, r = pair
+    src, pred, err = oracle_lib.map_wrap_cases()
+    assert np.array_equal(o.remap_map(src, pred, err), r.remap_map(src, pred, err))
+    L, R, coefs = oracle_lib.diverging_impulse_clip()
+    a = o.predict(2, L, R, coefs=coefs)
+    b = r.predict(2, L, R, coefs=coefs)
+    assert a["e0"].min() == -2 ** 31 and (a["u0"] < 0).any()   # the case is what it claims to be
+    for k in ("e0", "e1", "u0", "u1"):
+        assert np.array_equal(a[k], b[k]), k
+    p0 = L - a["e0"]
+    assert np.array_equal(o.remap_map(L, p0, a["e0"]), r.remap_map(L, p0, a["e0"]))
+
+
 def test_optimize_with_cost_mean_rms(pair):
     # FrameCoder::Optimize's schedule driven with the reference's OTHER CostFunction, CostMeanRMS (codec.cpp:302-312)
     o, r = pair
