@@ -1426,7 +1426,15 @@ __global__ __launch_bounds__(L1_NT) void k_lms1c(const LmsJob *__restrict__ jobs
 #define LPC_TRI_(N) ((N) * ((N) + 1) / 2)
 #define LPC_SNAP_(N) (LPC_TRI_(N) + (N))
 #define LPC_COV_NT(N) (((LPC_SNAP_(N) + 63) / 64) * 64) /* threads of k_cov: one per covariance / b element (384, 576) */
-__device__ __forceinline__ int32_t s2u(int32_t v) { return v < 0 ? 2 * (-v) : (v > 0 ? 2 * v - 1 : 0); }
+// MathUtils::S2U (utils.h:56-61). Beyond |v| = 2^30 (a diverged filter) the reference's `2 * (-val)` / `2 * val - 1` overflow;
+// its build wraps (oracle/Makefile: -fwrapv, pinned in tests/test_oracle_vs_ref.py), so the arithmetic here is modulo 2^32 by
+// construction -- as signed expressions the compiler could assume the result non-negative.
+__device__ __forceinline__ int32_t s2u(int32_t v) {
+  const uint32_t x = (uint32_t)v;
+  return v < 0 ? (int32_t)(2u * (0u - x)) : (v > 0 ? (int32_t)(2u * x - 1u) : 0);
+}
+// abs() of <cstdlib> as the reference's build computes it: |INT32_MIN| stays INT32_MIN
+__device__ __forceinline__ int32_t abs_wrap(int32_t v) { return v < 0 ? (int32_t)(0u - (uint32_t)v) : v; }
 
 // hist[i] at time t for channel ch (cov.h:44-47 shifts expressed as indices into the inputs)
 template <int S>
@@ -1797,7 +1805,7 @@ __global__ __launch_bounds__(64) void k_mix(const MixJob *__restrict__ jobs, int
 #pragma unroll
       for (int k = 0; k < NS; k++) p += h[k] * w[k];  // RLS::Predict (rls.cpp:67-72)
       const int32_t q = cvt_i32_x86(round(cp0 + p));
-      const int32_t e = v - q;
+      const int32_t e = (int32_t)((uint32_t)v - (uint32_t)q);  // (q = INT32_MIN from a diverged filter: wraps like the reference's build)
       const int32_t ue = s2u(e);
       if (writer) {
         if (eo) eo[t] = e;
@@ -2032,7 +2040,7 @@ __global__ __launch_bounds__(256) void k_meanrms_batch(const int32_t *const *__r
   const int32_t *e = bufs[blockIdx.x];
   const int n = ns[blockIdx.x];
   long long s = 0;
-  for (int i = threadIdx.x; i < n; i += 256) { const int v = e[i]; s += v < 0 ? -(long long)v : v; }
+  for (int i = threadIdx.x; i < n; i += 256) s += abs_wrap(e[i]);  // (codec.cpp:307: abs of an int)
   red[threadIdx.x] = s;
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -2052,7 +2060,7 @@ __global__ void k_meanrms(const int32_t *e, int n, double *out) {
   // CostMeanRMS::Calc (codec.cpp:302-312): sum of |e| as integers (exact in FP64), / n
   __shared__ long long red[256];
   long long s = 0;
-  for (int i = threadIdx.x; i < n; i += 256) { const int v = e[i]; s += v < 0 ? -(long long)v : v; }
+  for (int i = threadIdx.x; i < n; i += 256) s += abs_wrap(e[i]);  // (codec.cpp:307: abs of an int)
   red[threadIdx.x] = s;
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -2109,7 +2117,7 @@ __global__ void k_map_apply(const MapJob *jobs) {  // Remap::Map + S2U + running
   int mx = 0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < job.n; i += gridDim.x * blockDim.x) {
     const int err = job.e[i];
-    const int pred = job.sw[i] - err;  // codec.cpp:175
+    const int pred = (int)((uint32_t)job.sw[i] - (uint32_t)err);  // codec.cpp:175 (wraps when err did)
     // Map's loop visits pred + sgn * i for i = 1..|err| (map.cpp:141-152). A diverged filter's prediction can be anything in int32
     // (cvt_i32_x86 gives INT32_MIN out of range) and err = val - pred wraps with it, so the walk may run over the end of int32
     // and come back at the other: the reference's `pred + sgn * i` is signed overflow there (undefined; its build wraps, and so

@@ -35,7 +35,7 @@ __device__ __forceinline__ int kth_set_bit(uint32_t x, int k) {
 __device__ __forceinline__ int unmap_wave(const uint32_t *mp, int pred, int merr, int lane) {
   if (merr == 0) return 0;
   const uint32_t *bw = mp, *rk = mp + UN_MAPW;
-  const int sgn = merr < 0 ? -1 : 1, need = merr < 0 ? -merr : merr;
+  const int sgn = merr < 0 ? -1 : 1, need = merr < 0 ? (int)(0u - (uint32_t)merr) : merr;  // (-INT32_MIN stays INT32_MIN, as in the reference's build)
   const int total = (int)rk[2049];
   const long long ip = (long long)pred + 32768;  // position of pred
   auto rank_le = [&](long long x) -> int {      // set bits at positions <= x
@@ -44,10 +44,12 @@ __device__ __forceinline__ int unmap_wave(const uint32_t *mp, int pred, int merr
     const int w = (int)(x >> 5), b = (int)(x & 31);
     return (int)rk[w] + __popc(bw[w] & (0xffffffffu >> (31 - b)));
   };
-  int kglob, w0;
-  if (sgn > 0) { kglob = rank_le(ip) + need; w0 = ip + 1 < 0 ? 0 : (ip + 1 > 65536 ? 2048 : (int)((ip + 1) >> 5)); }
-  else { kglob = rank_le(ip - 1) - need + 1; w0 = ip - 1 < 0 ? 0 : (ip - 1 > 65536 ? 2048 : (int)((ip - 1) >> 5)); }
-  if (kglob < 1 || kglob > total) return sgn * (4 * 32768 + 1);
+  long long kg;
+  int w0;
+  if (sgn > 0) { kg = (long long)rank_le(ip) + need; w0 = ip + 1 < 0 ? 0 : (ip + 1 > 65536 ? 2048 : (int)((ip + 1) >> 5)); }
+  else { kg = (long long)rank_le(ip - 1) - need + 1; w0 = ip - 1 < 0 ? 0 : (ip - 1 > 65536 ? 2048 : (int)((ip - 1) >> 5)); }
+  if (kg < 1 || kg > total) return sgn * (4 * 32768 + 1);  // (need = INT32_MIN, from merr = INT32_MIN, ends here too: the oracle's walk never counts down to it)
+  const int kglob = (int)kg;
   // word holding the kglob-th set bit: probe 64 words from w0 in the walking direction, else bisect the counts
   int w = w0 + sgn * lane;
   const bool in = w >= 0 && w <= 2048;

@@ -370,6 +370,15 @@ def test_predict_diverged_filter_beyond_int32(ctx, oracle):
     for g in got:
         for k in ("e0", "e1", "u0", "u1", "m0", "m1", "maxbpn"):
             assert np.array_equal(g[k], ref[k]), k
+    # the cost functions on wrapped residuals, alone and through GetCost on a window
+    for k in ("e0", "e1"):
+        assert same_bits(np.array(ctx.cost_golomb(ref[k], 1.5)), np.array(oracle.cost_golomb(ref[k], 1.5))), k
+        assert same_bits(np.array(ctx.cost_golomb_noalloc(ref[k], 1.5)), np.array(oracle.cost_golomb(ref[k], 1.5))), k
+        assert same_bits(np.array([ctx.cost_meanrms(ref[k])]), np.array([oracle.cost_meanrms(ref[k])])), k
+    costs, st = ctx.get_costs(2, [(L, R)], coefs[None, None], frm=[0], n=[len(L)], state=[0.5])
+    c1, mean = oracle.cost_golomb(ref["e0"], 0.5)
+    c2, mean = oracle.cost_golomb(ref["e1"], mean)
+    assert same_bits(costs[0], np.array([(c1 + c2) / 2.])) and same_bits(st, np.array([mean]))
     # the coded size of such a buffer: planes maxbpn..0 of the two's-complement bits
     import ctypes as C
     sz = ctx.coded_sizes([ref["u0"], ref["u1"]], [int(ref["maxbpn"][0]), int(ref["maxbpn"][1])])

@@ -244,6 +244,12 @@ def test_remap_map_beyond_int32(pair):
         assert np.array_equal(a[k], b[k]), k
     p0 = L - a["e0"]
     assert np.array_equal(o.remap_map(L, p0, a["e0"]), r.remap_map(L, p0, a["e0"]))
+    # the cost functions on such residuals: s2u wraps negative, abs(INT32_MIN) stays negative
+    for k in ("e0", "e1"):
+        assert o.cost_golomb(a[k], 1.5) == r.cost_golomb(a[k], 1.5), k
+        assert o.cost_meanrms(a[k]) == r.cost_meanrms(a[k]), k
+    z = np.array([5, -2 ** 31, -7, 2 ** 30, -2 ** 30 - 3], np.int32)
+    assert o.cost_meanrms(z) == r.cost_meanrms(z) == 3.0 and o.cost_golomb(z, 0.) == r.cost_golomb(z, 0.)
 
 
 def test_optimize_with_cost_mean_rms(pair):

@@ -6,6 +6,8 @@ edge of the kernels (8, 32, 64, 256, 512, 2048, 4096, 7056, 16384) and random on
   unpredict plain residuals, and mapped ones with the tables of Remap::Analyse      == oracle and == the input samples
   optimize  a few short clips, random number of optimised coefficients                == oracle: winners and cost trace
   coded sizes of the plain and mapped s2u buffers of every clip                       == oracle coder's byte counts
+  get_costs on random windows with carried state, cost_golomb / _noalloc / cost_meanrms on raw buffers, the decoder on
+  residuals no encoder wrote (clamp, Unmap tables), encode in both modes and Optimize with the other two cost functions
 usage: fuzz_parity.py [seed] [rounds] [clips per round]      (test infrastructure: it uses the oracle)"""
 import ctypes as C
 import os, sys, time
@@ -133,6 +135,76 @@ with sacopt.Context(0, tab, bits) as ctx:
                     for j, i in enumerate(pick):
                         ob, ot = orc.optimize(prof, *clips[i], ncoef_loop=ncl)
                         check(best[j].tobytes() == ob[:best.shape[1]].tobytes() and traces[j].tobytes() == ot.tobytes(), "optimize", prof, i, kinds[i], lens[i], ncl)
+            # ---- the other entry points, on a few clips of this round
+            small = [i for i in range(nclips) if 200 <= lens[i] <= 9000][:5]
+            if small:
+                fr = [clips[i] for i in small]
+                # GetCost on windows, several candidates per frame, carried running mean (codec.cpp:342-352, 315-339)
+                ncand = int(rs.randint(1, 5))
+                cands = np.array([[[(v[2] if rs.rand() < 0.5 else v[0] + rs.rand() * (v[1] - v[0])) for v in base] for _ in range(ncand)] for _ in small])
+                frm = [int(rs.randint(0, len(c[0]) // 2)) for c in fr]
+                nn = [int(rs.randint(1, len(c[0]) - f + 1)) for c, f in zip(fr, frm)]
+                st0 = rs.rand(len(small)) * 8
+                costs, st = ctx.get_costs(prof, fr, cands, frm=frm, n=nn, state=st0)
+                for j, (L, R) in enumerate(fr):
+                    mean = float(st0[j])
+                    for k in range(ncand):
+                        r = orc.predict(prof, L, R, frm=frm[j], n=nn[j], coefs=cands[j, k])
+                        c1, mean = orc.cost_golomb(r["e0"], mean)
+                        c2, mean = orc.cost_golomb(r["e1"], mean)
+                        okc = np.array([(c1 + c2) / 2.]).tobytes() == costs[j, k:k + 1].tobytes()
+                        check(okc, "get_costs", prof, small[j], kinds[small[j]], frm[j], nn[j], k, "got", costs[j, k], "want", (c1 + c2) / 2., c1, c2)
+                        if not okc:
+                            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                            np.savez(os.path.join(ROOT, "gpurun_out", f"fuzz_getcosts_{seed}_{rnd}_{prof}_{small[j]}_{k}.npz"), L=L, R=R, cand=cands[j, k], frm=frm[j], n=nn[j],
+                                     st0=st0[j], e0=r["e0"], e1=r["e1"])
+                    check(np.array([mean]).tobytes() == st[j:j + 1].tobytes(), "get_costs state", prof, small[j])
+                # the cost functions on raw buffers (residuals of a diverged filter included)
+                for j in small[:3]:
+                    for key in ("e0", "e1"):
+                        b = refs[j][key]; s0_ = float(rs.rand() * 5)
+                        g = ctx.cost_golomb(b, s0_); w = orc.cost_golomb(b, s0_)
+                        check(np.array(g).tobytes() == np.array(w).tobytes(), "cost_golomb", prof, j, kinds[j], len(b))
+                        g = ctx.cost_golomb_noalloc(b, s0_)
+                        check(np.array(g).tobytes() == np.array(w).tobytes(), "cost_golomb_noalloc", prof, j, kinds[j], len(b))
+                        check(np.float64(ctx.cost_meanrms(b)).tobytes() == np.float64(orc.cost_meanrms(b)).tobytes(), "cost_meanrms", prof, j, kinds[j], len(b))
+                # the decoder on residuals that no encoder wrote, with the high profile's clamp and Unmap tables
+                if prof in (1, 2):
+                    gfr = []
+                    for j in small[:3]:
+                        n_ = min(len(clips[j][0]), 1500)
+                        amp = int(rs.choice([3, 300, 40000, 2 ** 31 - 1]))
+                        g = dict(e0=rs.randint(-amp, amp + 1, n_).astype(np.int32), e1=rs.randint(-amp // 2 - 1, amp // 2 + 2, n_).astype(np.int32))
+                        if amp > 40000: g["e0"][rs.randint(0, n_, 3)] = -2 ** 31
+                        if rs.rand() < 0.5: g["used0"] = orc.remap_tables(clips[j][0])
+                        if rs.rand() < 0.5: g["used1"] = orc.remap_tables(clips[j][1])
+                        if prof == 2 and rs.rand() < 0.7: g["minmax"] = (int(rs.randint(-40000, 0)), int(rs.randint(0, 40000)), int(rs.randint(-40000, 0)), int(rs.randint(0, 40000)))
+                        gfr.append(g)
+                    dg = ctx.unpredict(prof, gfr, coefs=coefs[small[:3]])
+                    for j, g, v in zip(small[:3], gfr, dg):
+                        o = orc.unpredict(prof, g["e0"], g["e1"], coefs=coefs[j], used0=g.get("used0"), used1=g.get("used1"), minmax=g.get("minmax"))
+                        check(np.array_equal(v[0], o[0]) and np.array_equal(v[1], o[1]), "unpredict garbage", prof, j, len(g["e0"]), sorted(g.keys()))
+            # FrameCoder::Predict with Optimize enabled, both modes, and the other two cost functions (short clips: the oracle is slow)
+            if prof < 3:
+                tiny = [i for i in range(nclips) if 64 <= lens[i] <= 2500 and kinds[i] in (0, 4, 5, 6)][:2]
+                if tiny:
+                    ncl = int(rs.randint(1, sacopt.NCOEF[prof] + 1))
+                    fr = [clips[i] for i in tiny]
+                    for sel in (False, True):
+                        best, outs = ctx.encode(prof, fr, ncoef_loop=ncl, maps=True, selected=sel)
+                        for j, i in enumerate(tiny):
+                            ob, _ = orc.optimize(prof, *clips[i], ncoef_loop=ncl)
+                            check(best[j].tobytes() == ob[:best.shape[1]].tobytes(), "encode winners", prof, i, sel, ncl)
+                            r = orc.predict(prof, *clips[i], coefs=(ob[:best.shape[1]] if sel else None), maps=True)
+                            for k in KEYS:
+                                check(np.array_equal(outs[j][k], r[k]), "encode residuals", prof, i, sel, k)
+                    cf = int(rs.randint(1, 3))
+                    ctx.set_cost_function(cf)
+                    best, traces, _ = ctx.optimize(prof, fr, ncoef_loop=ncl)
+                    ctx.set_cost_function(0)
+                    for j, i in enumerate(tiny):
+                        ob, ot = orc.optimize(prof, *clips[i], ncoef_loop=ncl, cost_fn=cf)
+                        check(best[j].tobytes() == ob[:best.shape[1]].tobytes() and traces[j].tobytes() == ot.tobytes(), "optimize cost_fn", prof, i, cf, ncl)
             print(f"round {rnd} profile {prof}: {nclips} clips, {sum(lens)} samples, {time.time() - t:.1f} s, mismatches so far {bad}", flush=True)
 print("FUZZ", "FAILED" if bad else "ok")
 sys.exit(1 if bad else 0)
