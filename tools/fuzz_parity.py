@@ -205,6 +205,14 @@ with sacopt.Context(0, tab, bits) as ctx:
                     for j, i in enumerate(tiny):
                         ob, ot = orc.optimize(prof, *clips[i], ncoef_loop=ncl, cost_fn=cf)
                         check(best[j].tobytes() == ob[:best.shape[1]].tobytes() and traces[j].tobytes() == ot.tobytes(), "optimize cost_fn", prof, i, cf, ncl)
+            # a whole-batch Optimize (hundreds of chains per round: the shared stream sets, the lead stage's launch sequences)
+            if prof == 2:
+                many = [i for i in range(nclips) if 64 <= lens[i] <= 4000]
+                if len(many) > 16:
+                    best, traces, _ = ctx.optimize(prof, [clips[i] for i in many])
+                    for j, i in enumerate(many):
+                        ob, ot = orc.optimize(prof, *clips[i])
+                        check(best[j].tobytes() == ob[:best.shape[1]].tobytes() and traces[j].tobytes() == ot.tobytes(), "optimize batch", prof, i, kinds[i], lens[i], len(many))
             print(f"round {rnd} profile {prof}: {nclips} clips, {sum(lens)} samples, {time.time() - t:.1f} s, mismatches so far {bad}", flush=True)
 print("FUZZ", "FAILED" if bad else "ok")
 sys.exit(1 if bad else 0)
