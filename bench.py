@@ -142,10 +142,11 @@ def large_batch_extra(ctx, torch, dev, stereo_clip, sacopt, nfr=TRACK_FRAMES):
             "unit": "samples/s", "checked_against_separate_calls": ok}
 
 
-def two_channel_extra(ctx, torch, dev, stereo_clip, sacopt, nch=21, n=16384):
-    """Not the headline: serial latency of the OTHER (1280,640) kernel -- both channels of a chain in one workgroup, what every
-    launch of more than 20 chains uses (the optimizer's rounds, large batches) -- from a full-frame pass of 21 short frames: its
-    lead stage is then that kernel, one workgroup per CU, and the library times those launches."""
+def two_channel_extra(ctx, torch, dev, stereo_clip, sacopt, nch=L1C_FRAMES + 1, n=20480):
+    """Not the headline: serial latency of the OTHER (1280,640) kernel, k_lms2 -- both channels of a chain in one workgroup, what
+    the optimizer's rounds (more than 20 chains) and calls of more than 48 frames use -- from a full-frame pass of 49 short
+    frames: its lead stage is then that kernel, one workgroup per CU beside the follower stages, and the library times those
+    launches."""
     L, R = stereo_clip(3000, nch * n)
     dL = torch.from_numpy(L).to(dev); dR = torch.from_numpy(R).to(dev)
     o = [torch.empty_like(dL) for _ in range(4)]   # (this extra times one kernel: no Remap outputs)
@@ -156,7 +157,7 @@ def two_channel_extra(ctx, torch, dev, stereo_clip, sacopt, nch=21, n=16384):
         ctx.predict(sacopt.PROFILE_HIGH, frames, device_out=outs)
     t = ctx.last_timing()
     per_chain = t["lms_units"] / nch
-    return {"kernel": "k_lms<1280,640,512,8,2048,true>", "workload": f"full-frame pass of {nch} frames x {n} samples", "launches": t["lms_launches"],
+    return {"kernel": "k_lms2", "workload": f"full-frame pass of {nch} frames x {n} samples", "launches": t["lms_launches"],
             "kernel_ms": t["lms_ms"], "cycles_per_sample_at_2.4GHz": t["lms_ms"] * 2.4e6 / per_chain if per_chain else None}
 
 
