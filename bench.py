@@ -354,6 +354,7 @@ def main():
                         f"= {tracks}/8 of BASELINE configs[3]'s per-GPU work (64 tracks on 8 GPUs), one library call per track; high profile, full "
                         f"optimizer population ({cand} GetCost per frame) + final full-frame predict with Remap outputs; frames sharded with "
                         f"frame_shard, per-frame rows all-gathered over {'RCCL' if args.backend == 'nccl' else args.backend}; range coding and file I/O excluded")
+        e2e_cores = 0
         line = {
             "metric": "encoded samples/sec (node) in optimize mode", "value": samples / dt if verified is not False else None, "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
@@ -410,12 +411,7 @@ def main():
                                       "serial_samples_per_s_derived": nfr * FRAME / (gpu_s + coder_s),
                                       "note": "host coder = the reference's FrameCoder::Encode() (bit-plane + range coder, unchanged, on the host); "
                                               "its time is " + how}
-                try:  # MEASURED end to end: the reference's own program with the batched, pipelined binding (tools/e2e_pipeline.py, own process)
-                    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "e2e_pipeline.py"), str(cores), "15"],
-                                         capture_output=True, text=True, timeout=400)
-                    line["end_to_end"]["measured"] = json.loads(out.stdout.strip().splitlines()[-1])
-                except Exception as e:
-                    line["end_to_end"]["measured"] = {"error": str(e)[:200]}
+                e2e_cores = cores   # (measured after this process has released its context, below)
         if world == 1 and nfr == NFRAMES and not args.no_extras:
             line["split"] = split_extra(ctx, torch, sacopt, b)
             line["apply_selected_parameters"] = apply_params_extra(ctx, torch, sacopt, b, nfr)
@@ -426,6 +422,18 @@ def main():
         if not args.no_decode and world == 1:
             ctx.encode(sacopt.PROFILE_HIGH, frames, device_out=outs)   # residuals of the clip back in the output buffers
             line["decode"] = decode_extra(ctx, torch, nfr, b["dL"], b["dR"], b["o"][0], b["o"][1])   # after the timed region, not part of `value`
+        if e2e_cores:
+            # MEASURED end to end: the reference's own program with the batched, pipelined binding (tools/e2e_pipeline.py, its own
+            # process and context). This process closes its context first: a context holds 19 hardware queues, and two
+            # processes' worth on one GPU is past the point where every call gets slower -- with this
+            # process's context alive the child's GPU calls took 0.95 s per batch instead of 0.42.
+            ctx.close()
+            try:
+                out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "e2e_pipeline.py"), str(e2e_cores), "15"],
+                                     capture_output=True, text=True, timeout=400)
+                line["end_to_end"]["measured"] = json.loads(out.stdout.strip().splitlines()[-1])
+            except Exception as e:
+                line["end_to_end"]["measured"] = {"error": str(e)[:200]}
         print(json.dumps(line), flush=True)
     ctx.close()
     if world > 1:
