@@ -1,6 +1,6 @@
 """Randomised differential run of the library against the C restatement (oracle/), wider than tests/ and tools/soak.py: all four
-profiles, random coefficient vectors inside the profile's ranges, eight signal families (tonal clip, silence, DC, full-scale
-square, sparse alphabets that switch Remap on, white noise, very quiet noise, impulses), lengths on and around every block
+profiles, random coefficient vectors inside the profile's ranges, ten signal families (tonal clip, silence, DC, full-scale
+square, sparse alphabets that switch Remap on, white noise, very quiet noise, impulses, 17-24 bit values, bursts), lengths on and around every block
 edge of the kernels (8, 32, 64, 256, 512, 2048, 4096, 7056, 16384) and random ones. Per round and profile:
   predict   one call of all clips AND single-clip calls (both (1280,640) kernels)   == oracle: e, u, m, maxbpn
   unpredict plain residuals, and mapped ones with the tables of Remap::Analyse      == oracle and == the input samples
@@ -54,6 +54,16 @@ def signal(kind, n):
     if kind == 6:
         r = np.random.RandomState(s)
         return r.randint(-3, 4, n).astype(np.int32), r.randint(-1, 2, n).astype(np.int32)
+    if kind == 8:   # beyond 16 bits: values outside Remap's +-32768 table ("val too large", map.cpp:116), predictions outside it
+        L, R = stereo_clip(s, n)
+        k0, k1 = int(rs.randint(2, 200)), int(rs.randint(2, 200))
+        return (L * k0).astype(np.int32), (R * k1).astype(np.int32)
+    if kind == 9:   # silence, then a burst, then silence again (adaptive stages wake up and decay)
+        L, R = stereo_clip(s, n)
+        a, b = sorted(int(x) for x in rs.randint(0, n + 1, 2))
+        L = L.copy(); R = R.copy()
+        L[:a] = 0; R[:a] = 0; L[b:] = 0; R[b:] = 0
+        return L, R
     r = np.random.RandomState(s)   # impulses on silence
     L = np.zeros(n, np.int32); R = np.zeros(n, np.int32)
     k = max(1, n // 97)
@@ -86,7 +96,7 @@ with sacopt.Context(0, tab, bits) as ctx:
             base = orc.base_profile(prof)
             lens = [int(rs.choice(EDGES)) if rs.rand() < 0.5 else int(rs.choice([rs.randint(1, 600), rs.randint(600, 5000), rs.randint(5000, 20000), rs.randint(20000, 45000)], p=[.3, .45, .2, .05]))
                     for _ in range(nclips)]
-            kinds = [int(rs.randint(0, 8)) for _ in range(nclips)]
+            kinds = [int(rs.randint(0, 10)) for _ in range(nclips)]
             clips = [signal(k, n) for k, n in zip(kinds, lens)]
             # one coefficient vector per clip: the profile's defaults or a random point of its ranges
             coefs = np.array([[(v[2] if rs.rand() < 0.3 else v[0] + rs.rand() * (v[1] - v[0])) for v in base] for _ in range(nclips)])
