@@ -8,7 +8,7 @@ edge of the kernels (8, 32, 64, 256, 512, 2048, 4096, 7056, 16384) and random on
   coded sizes of the plain and mapped s2u buffers of every clip                       == oracle coder's byte counts
   get_costs on random windows with carried state, cost_golomb / _noalloc / cost_meanrms on raw buffers, the decoder on
   residuals no encoder wrote (clamp, Unmap tables), encode in both modes and Optimize with the other two cost functions
-usage: fuzz_parity.py [seed] [rounds] [clips per round]      (test infrastructure: it uses the oracle)"""
+usage: fuzz_parity.py [seed] [rounds] [clips per round] [full-size frames]      (test infrastructure: it uses the oracle)"""
 import ctypes as C
 import os, sys, time
 import numpy as np
@@ -224,5 +224,31 @@ with sacopt.Context(0, tab, bits) as ctx:
                         ob, ot = orc.optimize(prof, *clips[i])
                         check(best[j].tobytes() == ob[:best.shape[1]].tobytes() and traces[j].tobytes() == ot.tobytes(), "optimize batch", prof, i, kinds[i], lens[i], len(many))
             print(f"round {rnd} profile {prof}: {nclips} clips, {sum(lens)} samples, {time.time() - t:.1f} s, mismatches so far {bad}", flush=True)
+    # ---- full-size frames (argv[4] of them): the chunk-pipelined full-frame pass with carried stage state, chunked optimizer windows
+    nbig = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+    if nbig:
+        t = time.time()
+        prof = 2
+        base = orc.base_profile(prof)
+        lens = [int(rs.randint(100000, 200001)) for _ in range(nbig)]
+        kinds = [int(rs.choice([0, 3, 4, 5, 7, 8, 9])) for _ in range(nbig)]
+        clips = [signal(k, n) for k, n in zip(kinds, lens)]
+        coefs = np.array([[(v[2] if rs.rand() < 0.5 else v[0] + rs.rand() * (v[1] - v[0])) for v in base] for _ in range(nbig)])
+        allres = ctx.predict(prof, clips, coefs=coefs, maps=True)
+        refs = [orc.predict(prof, L, R, coefs=coefs[i], maps=True) for i, (L, R) in enumerate(clips)]
+        for i in range(nbig):
+            for k in KEYS:
+                check(np.array_equal(allres[i][k], refs[i][k]), "big predict", i, kinds[i], lens[i], k)
+        dec = ctx.unpredict(prof, [dict(e0=r["e0"], e1=r["e1"]) for r in refs], coefs=coefs)
+        for i, (L, R) in enumerate(clips):
+            check(np.array_equal(dec[i][0], L) and np.array_equal(dec[i][1], R), "big unpredict round trip", i, kinds[i], lens[i])
+        best, outs = ctx.encode(prof, clips[:2], maps=True, selected=True)
+        for i in range(min(2, nbig)):
+            ob, _ = orc.optimize(prof, *clips[i])
+            check(best[i].tobytes() == ob[:best.shape[1]].tobytes(), "big encode winners", i, kinds[i], lens[i])
+            r = orc.predict(prof, *clips[i], coefs=ob[:best.shape[1]], maps=True)
+            for k in KEYS:
+                check(np.array_equal(outs[i][k], r[k]), "big encode residuals", i, kinds[i], lens[i], k)
+        print(f"big: {nbig} frames, {sum(lens)} samples, kinds {kinds}, {time.time() - t:.1f} s, mismatches so far {bad}", flush=True)
 print("FUZZ", "FAILED" if bad else "ok")
 sys.exit(1 if bad else 0)
