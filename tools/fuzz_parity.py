@@ -141,10 +141,15 @@ with sacopt.Context(0, tab, bits) as ctx:
                 pick = [i for i in range(nclips) if 64 <= lens[i] <= 6000][:4]
                 if pick:
                     ncl = int(rs.randint(1, sacopt.NCOEF[prof] + 1))
-                    best, traces, _ = ctx.optimize(prof, [clips[i] for i in pick], ncoef_loop=ncl)
+                    ptab = None
+                    if rs.rand() < 0.5:   # a profile table of the caller's: ranges shrunk around the defaults (the grid's length is decided by FP accumulation, codec.cpp:392)
+                        ptab = base.copy()
+                        ptab[:, 0] += rs.rand(len(base)) * (ptab[:, 2] - ptab[:, 0])
+                        ptab[:, 1] -= rs.rand(len(base)) * (ptab[:, 1] - ptab[:, 2])
+                    best, traces, _ = ctx.optimize(prof, [clips[i] for i in pick], prof=ptab, ncoef_loop=ncl)
                     for j, i in enumerate(pick):
-                        ob, ot = orc.optimize(prof, *clips[i], ncoef_loop=ncl)
-                        check(best[j].tobytes() == ob[:best.shape[1]].tobytes() and traces[j].tobytes() == ot.tobytes(), "optimize", prof, i, kinds[i], lens[i], ncl)
+                        ob, ot = orc.optimize(prof, *clips[i], prof=ptab, ncoef_loop=ncl)
+                        check(best[j].tobytes() == ob[:best.shape[1]].tobytes() and traces[j].tobytes() == ot.tobytes(), "optimize", prof, i, kinds[i], lens[i], ncl, ptab is not None)
             # ---- the other entry points, on a few clips of this round
             small = [i for i in range(nclips) if 200 <= lens[i] <= 9000][:5]
             if small:
