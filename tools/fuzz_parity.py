@@ -18,21 +18,11 @@ import oracle_lib
 from sac_amd import sacopt
 from sac_amd.synth import stereo_clip
 
-seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 2
-nclips = int(sys.argv[3]) if len(sys.argv) > 3 else 40
-rs = np.random.RandomState(seed)
-oracle_lib.build_oracle()
-orc = oracle_lib.Oracle()
-_t = np.load(os.path.join(ROOT, "tests", "golden", "rsqrt_table.npz"), allow_pickle=False)
-tab, bits = _t["tab"].astype(np.float32), int(_t["bits"])   # the fixture's rsqrtss table on both sides
-orc.set_rsqrt_table(tab, bits)
-
 EDGES = [1, 2, 7, 8, 9, 31, 32, 33, 63, 64, 65, 255, 256, 257, 511, 512, 513, 1023, 1025, 2047, 2048, 2049, 4095, 4096, 4097,
          7055, 7056, 7057, 8192, 16383, 16384, 16385]
 
 
-def signal(kind, n):
+def signal(rs, kind, n):
     s = int(rs.randint(1, 1 << 30))
     if kind == 0:
         return stereo_clip(s, n)
@@ -75,21 +65,21 @@ def s2u_inv(u):   # utils.h:62-66
     return np.where(u & 1, ((u.astype(np.int64) + 1) >> 1), -(u.astype(np.int64) >> 1)).astype(np.int32)
 
 
-def coder_size(buf, maxbpn):
-    b = np.ascontiguousarray(buf, dtype=np.int32)
-    return orc.lib.oracle_encode_mono_normal(b.ctypes.data_as(C.c_void_p), C.c_int(len(b)), C.c_int(int(maxbpn)), None, C.c_int(0))
-
-
-bad = 0
-def check(ok, *what):
-    global bad
-    if not ok:
-        bad += 1
-        print("MISMATCH", *what, flush=True)
-
-
 KEYS = ("e0", "e1", "u0", "u1", "m0", "m1", "maxbpn")
-with sacopt.Context(0, tab, bits) as ctx:
+def fuzz(ctx, orc, seed, rounds, nclips, nbig=0, log=print):
+    """Returns the number of mismatches (each one logged). ctx and orc must use the same rsqrtss table."""
+    rs = np.random.RandomState(seed)
+    bad = [0]
+
+    def check(ok, *what):
+        if not ok:
+            bad[0] += 1
+            log("MISMATCH", *what)
+
+    def coder_size(buf, maxbpn):
+        b = np.ascontiguousarray(buf, dtype=np.int32)
+        return orc.lib.oracle_encode_mono_normal(b.ctypes.data_as(C.c_void_p), C.c_int(len(b)), C.c_int(int(maxbpn)), None, C.c_int(0))
+
     for rnd in range(rounds):
         for prof in (2, 1, 0, 3):
             t = time.time()
@@ -97,7 +87,7 @@ with sacopt.Context(0, tab, bits) as ctx:
             lens = [int(rs.choice(EDGES)) if rs.rand() < 0.5 else int(rs.choice([rs.randint(1, 600), rs.randint(600, 5000), rs.randint(5000, 20000), rs.randint(20000, 45000)], p=[.3, .45, .2, .05]))
                     for _ in range(nclips)]
             kinds = [int(rs.randint(0, 10)) for _ in range(nclips)]
-            clips = [signal(k, n) for k, n in zip(kinds, lens)]
+            clips = [signal(rs, k, n) for k, n in zip(kinds, lens)]
             # one coefficient vector per clip: the profile's defaults or a random point of its ranges
             coefs = np.array([[(v[2] if rs.rand() < 0.3 else v[0] + rs.rand() * (v[1] - v[0])) for v in base] for _ in range(nclips)])
             allres = ctx.predict(prof, clips, coefs=coefs, maps=True)
@@ -228,16 +218,15 @@ with sacopt.Context(0, tab, bits) as ctx:
                     for j, i in enumerate(many):
                         ob, ot = orc.optimize(prof, *clips[i])
                         check(best[j].tobytes() == ob[:best.shape[1]].tobytes() and traces[j].tobytes() == ot.tobytes(), "optimize batch", prof, i, kinds[i], lens[i], len(many))
-            print(f"round {rnd} profile {prof}: {nclips} clips, {sum(lens)} samples, {time.time() - t:.1f} s, mismatches so far {bad}", flush=True)
+            log(f"round {rnd} profile {prof}: {nclips} clips, {sum(lens)} samples, {time.time() - t:.1f} s, mismatches so far {bad[0]}")
     # ---- full-size frames (argv[4] of them): the chunk-pipelined full-frame pass with carried stage state, chunked optimizer windows
-    nbig = int(sys.argv[4]) if len(sys.argv) > 4 else 0
     if nbig:
         t = time.time()
         prof = 2
         base = orc.base_profile(prof)
         lens = [int(rs.randint(100000, 200001)) for _ in range(nbig)]
         kinds = [int(rs.choice([0, 3, 4, 5, 7, 8, 9])) for _ in range(nbig)]
-        clips = [signal(k, n) for k, n in zip(kinds, lens)]
+        clips = [signal(rs, k, n) for k, n in zip(kinds, lens)]
         coefs = np.array([[(v[2] if rs.rand() < 0.5 else v[0] + rs.rand() * (v[1] - v[0])) for v in base] for _ in range(nbig)])
         allres = ctx.predict(prof, clips, coefs=coefs, maps=True)
         refs = [orc.predict(prof, L, R, coefs=coefs[i], maps=True) for i, (L, R) in enumerate(clips)]
@@ -254,6 +243,21 @@ with sacopt.Context(0, tab, bits) as ctx:
             r = orc.predict(prof, *clips[i], coefs=ob[:best.shape[1]], maps=True)
             for k in KEYS:
                 check(np.array_equal(outs[i][k], r[k]), "big encode residuals", i, kinds[i], lens[i], k)
-        print(f"big: {nbig} frames, {sum(lens)} samples, kinds {kinds}, {time.time() - t:.1f} s, mismatches so far {bad}", flush=True)
-print("FUZZ", "FAILED" if bad else "ok")
-sys.exit(1 if bad else 0)
+        log(f"big: {nbig} frames, {sum(lens)} samples, kinds {kinds}, {time.time() - t:.1f} s, mismatches so far {bad[0]}")
+    return bad[0]
+
+
+if __name__ == "__main__":
+    seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+    nclips = int(sys.argv[3]) if len(sys.argv) > 3 else 40
+    nbig = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+    oracle_lib.build_oracle()
+    orc = oracle_lib.Oracle()
+    _t = np.load(os.path.join(ROOT, "tests", "golden", "rsqrt_table.npz"), allow_pickle=False)
+    tab, bits = _t["tab"].astype(np.float32), int(_t["bits"])   # the fixture's rsqrtss table on both sides
+    orc.set_rsqrt_table(tab, bits)
+    with sacopt.Context(0, tab, bits) as ctx:
+        nbad = fuzz(ctx, orc, seed, rounds, nclips, nbig, log=lambda *a: print(*a, flush=True))
+    print("FUZZ", "FAILED" if nbad else "ok")
+    sys.exit(1 if nbad else 0)
