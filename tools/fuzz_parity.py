@@ -127,7 +127,7 @@ def fuzz(ctx, orc, seed, rounds, nclips, nbig=0, log=print):
             for j in range(len(bufs)):
                 check(int(got[j]) == coder_size(bufs[j], mb[j]), "coded size", prof, j // 4, j % 4, len(bufs[j]), mb[j])
             # optimizer: a few short clips in one call
-            if prof < 3:
+            if True:
                 pick = [i for i in range(nclips) if 64 <= lens[i] <= 6000][:4]
                 if pick:
                     ncl = int(rs.randint(1, sacopt.NCOEF[prof] + 1))
@@ -190,7 +190,7 @@ def fuzz(ctx, orc, seed, rounds, nclips, nbig=0, log=print):
                         o = orc.unpredict(prof, g["e0"], g["e1"], coefs=coefs[j], used0=g.get("used0"), used1=g.get("used1"), minmax=g.get("minmax"))
                         check(np.array_equal(v[0], o[0]) and np.array_equal(v[1], o[1]), "unpredict garbage", prof, j, len(g["e0"]), sorted(g.keys()))
             # FrameCoder::Predict with Optimize enabled, both modes, and the other two cost functions (short clips: the oracle is slow)
-            if prof < 3:
+            if True:
                 tiny = [i for i in range(nclips) if 64 <= lens[i] <= 2500 and kinds[i] in (0, 4, 5, 6)][:2]
                 if tiny:
                     ncl = int(rs.randint(1, sacopt.NCOEF[prof] + 1))
