@@ -127,19 +127,18 @@ def fuzz(ctx, orc, seed, rounds, nclips, nbig=0, log=print):
             for j in range(len(bufs)):
                 check(int(got[j]) == coder_size(bufs[j], mb[j]), "coded size", prof, j // 4, j % 4, len(bufs[j]), mb[j])
             # optimizer: a few short clips in one call
-            if True:
-                pick = [i for i in range(nclips) if 64 <= lens[i] <= 6000][:4]
-                if pick:
-                    ncl = int(rs.randint(1, sacopt.NCOEF[prof] + 1))
-                    ptab = None
-                    if rs.rand() < 0.5:   # a profile table of the caller's: ranges shrunk around the defaults (the grid's length is decided by FP accumulation, codec.cpp:392)
-                        ptab = base.copy()
-                        ptab[:, 0] += rs.rand(len(base)) * (ptab[:, 2] - ptab[:, 0])
-                        ptab[:, 1] -= rs.rand(len(base)) * (ptab[:, 1] - ptab[:, 2])
-                    best, traces, _ = ctx.optimize(prof, [clips[i] for i in pick], prof=ptab, ncoef_loop=ncl)
-                    for j, i in enumerate(pick):
-                        ob, ot = orc.optimize(prof, *clips[i], prof=ptab, ncoef_loop=ncl)
-                        check(best[j].tobytes() == ob[:best.shape[1]].tobytes() and traces[j].tobytes() == ot.tobytes(), "optimize", prof, i, kinds[i], lens[i], ncl, ptab is not None)
+            pick = [i for i in range(nclips) if 64 <= lens[i] <= 6000][:4]
+            if pick:
+                ncl = int(rs.randint(1, sacopt.NCOEF[prof] + 1))
+                ptab = None
+                if rs.rand() < 0.5:   # a profile table of the caller's: ranges shrunk around the defaults (the grid's length is decided by FP accumulation, codec.cpp:392)
+                    ptab = base.copy()
+                    ptab[:, 0] += rs.rand(len(base)) * (ptab[:, 2] - ptab[:, 0])
+                    ptab[:, 1] -= rs.rand(len(base)) * (ptab[:, 1] - ptab[:, 2])
+                best, traces, _ = ctx.optimize(prof, [clips[i] for i in pick], prof=ptab, ncoef_loop=ncl)
+                for j, i in enumerate(pick):
+                    ob, ot = orc.optimize(prof, *clips[i], prof=ptab, ncoef_loop=ncl)
+                    check(best[j].tobytes() == ob[:best.shape[1]].tobytes() and traces[j].tobytes() == ot.tobytes(), "optimize", prof, i, kinds[i], lens[i], ncl, ptab is not None)
             # ---- the other entry points, on a few clips of this round
             small = [i for i in range(nclips) if 200 <= lens[i] <= 9000][:5]
             if small:
@@ -190,26 +189,25 @@ def fuzz(ctx, orc, seed, rounds, nclips, nbig=0, log=print):
                         o = orc.unpredict(prof, g["e0"], g["e1"], coefs=coefs[j], used0=g.get("used0"), used1=g.get("used1"), minmax=g.get("minmax"))
                         check(np.array_equal(v[0], o[0]) and np.array_equal(v[1], o[1]), "unpredict garbage", prof, j, len(g["e0"]), sorted(g.keys()))
             # FrameCoder::Predict with Optimize enabled, both modes, and the other two cost functions (short clips: the oracle is slow)
-            if True:
-                tiny = [i for i in range(nclips) if 64 <= lens[i] <= 2500 and kinds[i] in (0, 4, 5, 6)][:2]
-                if tiny:
-                    ncl = int(rs.randint(1, sacopt.NCOEF[prof] + 1))
-                    fr = [clips[i] for i in tiny]
-                    for sel in (False, True):
-                        best, outs = ctx.encode(prof, fr, ncoef_loop=ncl, maps=True, selected=sel)
-                        for j, i in enumerate(tiny):
-                            ob, _ = orc.optimize(prof, *clips[i], ncoef_loop=ncl)
-                            check(best[j].tobytes() == ob[:best.shape[1]].tobytes(), "encode winners", prof, i, sel, ncl)
-                            r = orc.predict(prof, *clips[i], coefs=(ob[:best.shape[1]] if sel else None), maps=True)
-                            for k in KEYS:
-                                check(np.array_equal(outs[j][k], r[k]), "encode residuals", prof, i, sel, k)
-                    cf = int(rs.randint(1, 3))
-                    ctx.set_cost_function(cf)
-                    best, traces, _ = ctx.optimize(prof, fr, ncoef_loop=ncl)
-                    ctx.set_cost_function(0)
+            tiny = [i for i in range(nclips) if 64 <= lens[i] <= 2500 and kinds[i] in (0, 4, 5, 6)][:2]
+            if tiny:
+                ncl = int(rs.randint(1, sacopt.NCOEF[prof] + 1))
+                fr = [clips[i] for i in tiny]
+                for sel in (False, True):
+                    best, outs = ctx.encode(prof, fr, ncoef_loop=ncl, maps=True, selected=sel)
                     for j, i in enumerate(tiny):
-                        ob, ot = orc.optimize(prof, *clips[i], ncoef_loop=ncl, cost_fn=cf)
-                        check(best[j].tobytes() == ob[:best.shape[1]].tobytes() and traces[j].tobytes() == ot.tobytes(), "optimize cost_fn", prof, i, cf, ncl)
+                        ob, _ = orc.optimize(prof, *clips[i], ncoef_loop=ncl)
+                        check(best[j].tobytes() == ob[:best.shape[1]].tobytes(), "encode winners", prof, i, sel, ncl)
+                        r = orc.predict(prof, *clips[i], coefs=(ob[:best.shape[1]] if sel else None), maps=True)
+                        for k in KEYS:
+                            check(np.array_equal(outs[j][k], r[k]), "encode residuals", prof, i, sel, k)
+                cf = int(rs.randint(1, 3))
+                ctx.set_cost_function(cf)
+                best, traces, _ = ctx.optimize(prof, fr, ncoef_loop=ncl)
+                ctx.set_cost_function(0)
+                for j, i in enumerate(tiny):
+                    ob, ot = orc.optimize(prof, *clips[i], ncoef_loop=ncl, cost_fn=cf)
+                    check(best[j].tobytes() == ob[:best.shape[1]].tobytes() and traces[j].tobytes() == ot.tobytes(), "optimize cost_fn", prof, i, cf, ncl)
             # a whole-batch Optimize (hundreds of chains per round: the shared stream sets, the lead stage's launch sequences)
             if prof == 2:
                 many = [i for i in range(nclips) if 64 <= lens[i] <= 4000]
