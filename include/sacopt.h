@@ -173,6 +173,20 @@ int sacopt_cost_meanrms(sacopt_ctx *ctx, const int32_t *buf, int n, double *cost
  * reference's signed maximum skips it): as in the reference, planes maxbpn[b]..0 of its two's-complement bits are coded. */
 int sacopt_coded_sizes(sacopt_ctx *ctx, int nbuf, const int32_t *const *s2u, const int32_t *n, const int32_t *maxbpn, int32_t *sizes);
 
+/* ---- the payload BYTES: FrameCoder::EncodeMonoFrame_Normal (src/codec.cpp:237-247) and EncodeMonoFrame_Mapped (:249-265) ----
+ * What the host's coder writes for one channel of one frame, on the device: BitplaneCoder::Encode (src/coder/vle.cpp:110-138)
+ * over RangeCoderSH (src/coder/range.cpp:52-90), for a mapped channel behind MapEncoder::Encode of its Remap tables
+ * (src/coder/map.cpp:3-72) through the same range coder. Buffer b: s2u[b][0..n[b]) with maxbpn[b] (0..30) as for
+ * sacopt_coded_sizes; used == NULL or used[b] == NULL: the plain variant (feed s2u_error, maxbpn); else used[b] = usedl[0..32768]
+ * then usedh[0..32768], one byte each (Remap's tables, as sacopt_dec_frame takes them): the mapped variant (feed
+ * s2u_error_map, maxbpn_map). out[b]: cap[b] bytes (host or device); sizes[b] = the payload's length -- bytes beyond cap[b] are
+ * dropped, so sizes[b] > cap[b] says the buffer was too small (n[b] * 4 + 8 KiB + 64 always fits the plain variant's planes and the
+ * map). FrameCoder::EncodeMonoFrame keeps the mapped payload unless the plain one is strictly smaller (codec.cpp:268-280): call with
+ * both variants of a channel and compare sizes. At most 8192 buffers per call; a frame's buffers are independent coders, so
+ * the call is as long as its longest buffer (a 176 400-sample channel: ~0.9 s) whatever their number, up to two per CU. */
+int sacopt_encode_payloads(sacopt_ctx *ctx, int nbuf, const int32_t *const *s2u, const int32_t *n, const int32_t *maxbpn,
+                           const uint8_t *const *used, uint8_t *const *out, const int32_t *cap, int32_t *sizes);
+
 /* ---- CostGolomb::Calc without any allocation ------------------------------------------------------------------
  * NO COUNTERPART IN THE REFERENCE. Same arguments, result and state handling as sacopt_cost_golomb, for callers that
  * cannot allocate: callable while allocation is forbidden -- for example while ANOTHER stream of the process is being

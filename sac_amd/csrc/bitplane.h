@@ -43,6 +43,18 @@ struct BpJob {
   const int32_t *buf;  // s2u residuals (non-negative), n entries
   int32_t n, maxbpn;
 };
+// ---- the payload BYTES (sacopt_encode_payloads): the range coder's state where one coder hands over to the next
+// (FrameCoder::EncodeMonoFrame_Mapped, codec.cpp:249-265: MapEncoder and BitplaneCoder write through ONE RangeCoderSH)
+struct RcState {
+  unsigned long long lowc;
+  uint32_t range, ffnum, cache, pos;
+};
+struct BpEmit {
+  uint8_t *out;         // payload bytes (device), cap of them; bytes beyond cap are dropped, the size still counts them
+  const uint8_t *used;  // null: plain variant; else usedl[0..32768] then usedh[0..32768] (Remap's tables): mapped variant
+  RcState *rc;          // mapped: where k_mapenc leaves the coder's state for k_bppipe<true>
+  int32_t cap, pad;
+};
 
 __device__ __forceinline__ int bp_clamp(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 __device__ __forceinline__ int bp_idiv32(int val, int s) { return val < 0 ? -(((-val) + (1 << (s - 1))) >> s) : (val + (1 << (s - 1))) >> s; }
@@ -339,7 +351,10 @@ __device__ __forceinline__ int bpp_clamp(int v, int lo, int hi) { return max(lo,
 #define BPP_STAGES 5
 #define BPP_NT (BPP_NCOD * BPP_STAGES * 64)
 #define BPP_SSE (32 * 2 * 33)
-__global__ __launch_bounds__(BPP_NT) void k_bppipe(const BpJob *__restrict__ jobs, int nbuf, BpTables tb, int32_t *__restrict__ sizes) {
+// EMIT: also write the bytes (stage S4: RangeCoderSH::ShiftLow's cache / carry / 0xFF-run logic, range.cpp:80-90, one byte store
+// by lane 0 per output byte), starting from the state k_mapenc left when the buffer is coded with its map in front.
+template <bool EMIT>
+__global__ __launch_bounds__(BPP_NT) void k_bppipe(const BpJob *__restrict__ jobs, int nbuf, BpTables tb, int32_t *__restrict__ sizes, const BpEmit *__restrict__ emit) {
   __shared__ int16_t fwd[BP_PSCALE];
   __shared__ uint16_t inv[(1 << BP_DBITS) + 2];  // [0] = 0 and [4097] = PSCALE - 1: LogDomain::Inv beyond its table (domain.h:33-38)
   __shared__ uint16_t divt[BP_DIVN];
@@ -384,13 +399,29 @@ __global__ __launch_bounds__(BPP_NT) void k_bppipe(const BpJob *__restrict__ job
   int curmix = -1, cw0 = 0, cw1 = 0, cw2 = 0;  // S2: the mixer used last and its weights
   uint32_t lbreg = 0;
   int wf0 = 0, wf1 = 0;
-  uint32_t range = 0xFFFFFFFFu, ffnum = 0;
+  uint32_t range = 0xFFFFFFFFu, ffnum = 0, cache = 0;
   unsigned long long lowc = 0;
   int pos = 0;
-  auto shift_low = [&]() {  // RangeCoderSH::ShiftLow (range.cpp:80-90), counting the bytes it would put
+  uint8_t *outp = nullptr;
+  int cap = 0;
+  if (EMIT && live) {
+    const BpEmit em = emit[b];
+    outp = em.out; cap = em.cap;
+    if (em.used) { const RcState r = *em.rc; range = r.range; ffnum = r.ffnum; cache = r.cache; lowc = r.lowc; pos = (int)r.pos; }
+  }
+  auto put = [&](uint32_t v) {  // BufIO::PutByte
+    if (lane == 0 && pos < cap) outp[pos] = (uint8_t)v;
+    pos++;
+  };
+  auto shift_low = [&]() {  // RangeCoderSH::ShiftLow (range.cpp:80-90); !EMIT: counting the bytes it would put
     const uint32_t carry = (uint32_t)(lowc >> 32), low = (uint32_t)lowc;
-    if (low < 0xFF000000u || carry) { pos += 1 + (int)ffnum; ffnum = 0; }
-    else ffnum++;
+    if (low < 0xFF000000u || carry) {
+      if constexpr (EMIT) {
+        put(cache + carry);
+        for (; ffnum != 0; ffnum--) put(carry - 1u);
+        cache = low >> 24;
+      } else { pos += 1 + (int)ffnum; ffnum = 0; }
+    } else ffnum++;
     lowc = (unsigned long long)(low << 8);
   };
   __syncthreads();
@@ -562,5 +593,115 @@ __global__ __launch_bounds__(BPP_NT) void k_bppipe(const BpJob *__restrict__ job
   if (live && stage == BPP_STAGES - 1) {
     for (int i = 0; i < 5; i++) shift_low();  // RangeCoderSH::Stop, range.cpp:60-63
     if (lane == 0) sizes[b] = pos;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// MapEncoder::Encode (src/coder/map.cpp:3-72, map.h:10-36): the used-value tables of a mapped channel, 2 x 32768 binary
+// decisions through four counters, a four-input mixer, one SSE stage, the final mixer and the range coder -- the front part of
+// FrameCoder::EncodeMonoFrame_Mapped's payload (codec.cpp:249-265). One wave per buffer; every value of the chain is
+// wave-uniform (the compiler keeps it in scalar registers), the tables of 64 values at a time are fetched a lane each.
+// 65 536 decisions of ~1k cycles: ~30 ms, all mapped buffers of a call side by side; the bit planes follow from the state
+// this kernel leaves in emit[b].rc (k_bppipe<true>).
+// ------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_mapenc(const BpEmit *__restrict__ emit, const int32_t *__restrict__ which, BpTables tb) {
+  __shared__ int16_t fwd[BP_PSCALE];
+  __shared__ uint16_t inv[(1 << BP_DBITS) + 2];
+  __shared__ uint16_t divt[BP_DIVN];
+  __shared__ uint32_t smap[2][BP_SSE_N + 2];  // SSENL's two maps: p1 | counter << 16
+  __shared__ uint16_t cnt[24];
+  __shared__ int wm[8][4];  // mixl[4], mixh[4]
+  const int lane = threadIdx.x;
+  const BpEmit em = emit[which[blockIdx.x]];
+  for (int i = lane; i < BP_PSCALE; i += 64) fwd[i] = tb.fwd[i];
+  for (int i = lane; i < (1 << BP_DBITS); i += 64) inv[i + 1] = tb.inv[i];
+  if (lane == 0) { inv[0] = 0; inv[(1 << BP_DBITS) + 1] = BP_PSCALE - 1; }
+  for (int i = lane; i < BP_DIVN; i += 64) divt[i] = (uint16_t)(BP_PSCALE / (i + 3));
+  if (lane <= BP_SSE_N) smap[0][lane] = smap[1][lane] = tb.sse_init[lane];
+  if (lane < 24) cnt[lane] = BP_PSCALE >> 1;
+  if (lane < 32) (&wm[0][0])[lane] = 0;
+  __syncthreads();
+  const int tscale = tb.tscale, xscale = tb.xscale;
+  const uint32_t xmagic = (uint32_t)((0x100000000ull + (uint32_t)xscale - 1) / (uint32_t)xscale);
+  auto divx = [&](int x) -> int { int q = (int)__umulhi((uint32_t)x, xmagic); q -= (q * xscale > x) ? 1 : 0; return q; };
+  auto dinv = [&](int x) -> int { return (int)inv[bpp_clamp(x, -(1 << (BP_DBITS - 1)) - 1, 1 << (BP_DBITS - 1)) + (1 << (BP_DBITS - 1)) + 1]; };
+  uint32_t range = 0xFFFFFFFFu, ffnum = 0, cache = 0;
+  unsigned long long lowc = 0;
+  int pos = 0;
+  uint8_t *outp = em.out;
+  const int cap = em.cap;
+  auto put = [&](uint32_t v) {
+    if (lane == 0 && pos < cap) outp[pos] = (uint8_t)v;
+    pos++;
+  };
+  auto shift_low = [&]() {  // range.cpp:80-90
+    const uint32_t carry = (uint32_t)(lowc >> 32), low = (uint32_t)lowc;
+    if (low < 0xFF000000u || carry) {
+      put(cache + carry);
+      for (; ffnum != 0; ffnum--) put(carry - 1u);
+      cache = low >> 24;
+    } else ffnum++;
+    lowc = (unsigned long long)(low << 8);
+  };
+  const uint8_t *ul = em.used, *uh = em.used + 32769;
+  int l1 = ul[0], h1 = uh[0], l2 = 0, h2 = 0;  // ul[i-1], uh[i-1], ul[i-2], uh[i-2]
+  int wf0 = 0, wf1 = 0, lb = 0;
+  for (int i0 = 1; i0 <= 1 << 15; i0 += 64) {
+    const int ulv = ul[i0 + lane], uhv = uh[i0 + lane];
+    for (int j = 0; j < 64; j++) {
+      const int cl = __builtin_amdgcn_readlane(ulv, j), ch = __builtin_amdgcn_readlane(uhv, j);
+#pragma unroll
+      for (int hi = 0; hi < 2; hi++) {
+        // PredictLow (map.cpp:8-20) / PredictHigh (:22-34)
+        const int ctx1 = hi ? h1 : l1, ctx2 = hi ? cl : h1, ctx3 = hi ? h2 : l2, bit = hi ? ch : cl, cb = hi ? 12 : 0;
+        const int a0 = cb + ctx1, a1 = cb + 2 + ctx2, a2 = cb + 4 + (ctx1 << 1) + ctx3, a3 = cb + 8 + (ctx1 << 1) + ctx2;
+        int *w = wm[(hi ? 4 : 0) + ctx1 + (ctx3 << 1)];
+        const int p0 = cnt[a0], p1 = cnt[a1], p2 = cnt[a2], p3 = cnt[a3];
+        const int x0 = fwd[p0], x1 = fwd[p1], x2 = fwd[p2], x3 = fwd[p3];
+        const int w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
+        const long long sum = (long long)(w0 * x0) + (long long)(w1 * x1) + (long long)(w2 * x2) + (long long)(w3 * x3);  // mixer.h:73-84
+        const int pm = bpp_clamp(dinv((int)bpp_idiv64(sum, BP_WBITS)), 1, BP_PSCALEm);
+        // PredictSSE (map.cpp:45-49): SSENL<32> (sse.h:106-118), then finalmix
+        int pq = (int)fwd[pm] + tscale;
+        pq = pq < 0 ? 0 : (pq > 2 * tscale ? 2 * tscale : pq);
+        const int q = divx(pq), pmod = pq - q * xscale;
+        const uint32_t v0 = smap[lb][q], v1 = smap[lb][q + 1];
+        const int ps = bpp_clamp(divx((int)(v0 & 0xffffu) * (xscale - pmod) + (int)(v1 & 0xffffu) * pmod), 1, BP_PSCALEm);
+        const int y0 = fwd[ps], y1 = fwd[pm];
+        const long long fs = (long long)(wf0 * y0) + (long long)(wf1 * y1);
+        const int pf = bpp_clamp(dinv((int)bpp_idiv64(fs, BP_WBITS)), 1, BP_PSCALEm);
+        // RangeCoderSH::EncodeBitOne (range.cpp:65-70)
+        const uint32_t rnew = (uint32_t)(((unsigned long long)range * ((uint32_t)(BP_PSCALE - pf) << (32 - BP_PBITS))) >> 32);
+        if (bit) { range -= rnew; lowc += rnew; } else range = rnew;
+        while (range < 0x01000000u) { range <<= 8; shift_low(); }
+        // Update (map.cpp:36-43): counters rate 500, mixer rate 1000; UpdateSSE (:51-55): limit 300, finalmix rate 500
+        auto lc = [&](int a, int p) { cnt[a] = (uint16_t)bpp_clamp(p + bpp_idiv32(__mul24(500, (bit << BP_PBITS) - p), BP_PBITS), 1, BP_PSCALEm); };
+        lc(a0, p0); lc(a1, p1); lc(a2, p2); lc(a3, p3);
+        const int err = (bit << BP_PBITS) - pm;
+        w[0] = bpp_clamp(w0 + bpp_idiv32(__mul24(bpp_idiv32(x0 * err, BP_DBITS), 1000), BP_DBITS), -BP_WRANGE, BP_WRANGE - 1);
+        w[1] = bpp_clamp(w1 + bpp_idiv32(__mul24(bpp_idiv32(x1 * err, BP_DBITS), 1000), BP_DBITS), -BP_WRANGE, BP_WRANGE - 1);
+        w[2] = bpp_clamp(w2 + bpp_idiv32(__mul24(bpp_idiv32(x2 * err, BP_DBITS), 1000), BP_DBITS), -BP_WRANGE, BP_WRANGE - 1);
+        w[3] = bpp_clamp(w3 + bpp_idiv32(__mul24(bpp_idiv32(x3 * err, BP_DBITS), 1000), BP_DBITS), -BP_WRANGE, BP_WRANGE - 1);
+        auto lcl = [&](uint32_t v) -> uint32_t {  // LinearCounterLimit::update, counter.h:57-65
+          int pp = (int)(v & 0xffffu);
+          const int c2 = min((int)(v >> 16) + 1, 300);
+          const int dv = (int)divt[c2];
+          const int dp = bit ? ((BP_PSCALE - pp) * dv) >> BP_PBITS : -((pp * dv) >> BP_PBITS);
+          pp = bpp_clamp(pp + dp, 1, BP_PSCALEm);
+          return (uint32_t)pp | ((uint32_t)c2 << 16);
+        };
+        smap[lb][q] = lcl(v0); smap[lb][q + 1] = lcl(v1);
+        lb = bit;
+        const int ef = (bit << BP_PBITS) - pf;
+        wf0 = bpp_clamp(wf0 + bpp_idiv32(__mul24(bpp_idiv32(y0 * ef, BP_DBITS), 500), BP_DBITS), -BP_WRANGE, BP_WRANGE - 1);
+        wf1 = bpp_clamp(wf1 + bpp_idiv32(__mul24(bpp_idiv32(y1 * ef, BP_DBITS), 500), BP_DBITS), -BP_WRANGE, BP_WRANGE - 1);
+      }
+      l2 = l1; h2 = h1; l1 = cl; h1 = ch;
+    }
+  }
+  if (lane == 0) {
+    RcState r;
+    r.lowc = lowc; r.range = range; r.ffnum = ffnum; r.cache = cache; r.pos = (uint32_t)pos;
+    *em.rc = r;
   }
 }

@@ -2370,7 +2370,7 @@ extern "C" int sacopt_launch_bpsize(const BpJob *jobs, int nbuf, int maxn, int m
   // the stage-pipeline form (bitplane.h): up to 16 workgroup rounds of two coders per CU; beyond that the lane-per-coder forms
   // move more decisions per CU
   if (BP_PIPE && nbuf <= BP_PIPE_MAX) {
-    hipLaunchKernelGGL(k_bppipe, dim3((nbuf + BPP_NCOD - 1) / BPP_NCOD), dim3(BPP_NT), 0, st, jobs, nbuf, tbp, sizes);
+    hipLaunchKernelGGL(k_bppipe<false>, dim3((nbuf + BPP_NCOD - 1) / BPP_NCOD), dim3(BPP_NT), 0, st, jobs, nbuf, tbp, sizes, (const BpEmit *)nullptr);
     return hipGetLastError() != hipSuccess;
   }
   const int nblk = (nbuf + 63) / 64;
@@ -2381,6 +2381,18 @@ extern "C" int sacopt_launch_bpsize(const BpJob *jobs, int nbuf, int maxn, int m
   if (nbuf <= BP_WPC_MAX) hipLaunchKernelGGL((k_bpsize<8, true>), dim3((nbuf + 7) / 8), dim3(512), 0, st, jobs, nbuf, maxn, maxplanes, T, msb, sse, lb, tb, sizes);
   else if (nbuf <= BP_LAT_MAX) hipLaunchKernelGGL((k_bpsize<8>), dim3((nbuf + 7) / 8), dim3(64), 0, st, jobs, nbuf, maxn, maxplanes, T, msb, sse, lb, tb, sizes);
   else hipLaunchKernelGGL((k_bpsize<64>), dim3(nblk), dim3(64), 0, st, jobs, nbuf, maxn, maxplanes, T, msb, sse, lb, tb, sizes);
+  return hipGetLastError() != hipSuccess;
+}
+// the payload bytes (sacopt_encode_payloads): the map tables of the mapped buffers first (k_mapenc, which[0..nmapped) = their
+// indices), then every buffer's bit planes from the state that left (k_bppipe<true>)
+extern "C" int sacopt_launch_payloads(const BpJob *jobs, const BpEmit *emit, int nbuf, const int32_t *which, int nmapped,
+                                      const int16_t *fwd, const uint16_t *inv, const uint16_t *sse_init, int tscale, int xscale, int32_t *sizes,
+                                      hipStream_t st) {
+  if (nbuf <= 0) return 0;
+  if (nbuf > BP_PIPE_MAX) return 1;
+  BpTables tbp = {fwd, inv, sse_init, tscale, xscale};
+  if (nmapped > 0) hipLaunchKernelGGL(k_mapenc, dim3(nmapped), dim3(64), 0, st, emit, which, tbp);
+  hipLaunchKernelGGL(k_bppipe<true>, dim3((nbuf + BPP_NCOD - 1) / BPP_NCOD), dim3(BPP_NT), 0, st, jobs, nbuf, tbp, sizes, emit);
   return hipGetLastError() != hipSuccess;
 }
 extern "C" int sacopt_launch_map(const MapJob *jobs, int njobs, int max_numsamples, int max_n, hipStream_t st) {

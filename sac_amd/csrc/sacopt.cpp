@@ -63,6 +63,11 @@ int sacopt_launch_sumkat(int nterms, const double *x, int count, double *out, hi
 int sacopt_launch_map(const MapJob *jobs, int njobs, int max_numsamples, int max_n, hipStream_t st);
 int sacopt_launch_unpredict(int type, const UnJob *jobs, int njobs, const uint16_t *tab, int bits, hipStream_t st);
 struct BpJob { const int32_t *buf; int32_t n, maxbpn; };
+struct RcState { unsigned long long lowc; uint32_t range, ffnum, cache, pos; };
+struct BpEmit { uint8_t *out; const uint8_t *used; RcState *rc; int32_t cap, pad; };
+extern "C" int sacopt_launch_payloads(const BpJob *jobs, const BpEmit *emit, int nbuf, const int32_t *which, int nmapped,
+                                      const int16_t *fwd, const uint16_t *inv, const uint16_t *sse_init, int tscale, int xscale, int32_t *sizes,
+                                      hipStream_t st);
 int sacopt_launch_bpsize(const BpJob *jobs, int nbuf, int maxn, int maxplanes, int32_t *T, uint8_t *msb, uint32_t *sse, uint8_t *lb,
                          const int16_t *fwd, const uint16_t *inv, const uint16_t *sse_init, int tscale, int xscale, int32_t *sizes, hipStream_t st);
 int sacopt_launch_meanrms_batch(const int32_t *const *bufs, const int32_t *ns, int nbuf, double *out, hipStream_t st);
@@ -2259,6 +2264,63 @@ extern "C" int sacopt_coded_sizes(sacopt_ctx *c, int nbuf, const int32_t *const 
   HIPCK(c, hipEventRecord(b2, c->st));
   c->lms_ev.push_back({a, b2});
   HIPCK(c, hipMemcpyAsync(sizes, dsz, (size_t)nbuf * 4, hipMemcpyDeviceToHost, c->st));
+  return end_timing(c);
+}
+
+// ------------------------------------------------------------------------------------------ the payload bytes themselves
+// FrameCoder::EncodeMonoFrame_Normal / _Mapped (codec.cpp:237-265) on the device: include/sacopt.h
+extern "C" int sacopt_encode_payloads(sacopt_ctx *c, int nbuf, const int32_t *const *s2u, const int32_t *n, const int32_t *maxbpn,
+                                      const uint8_t *const *used, uint8_t *const *out, const int32_t *cap, int32_t *sizes) {
+  if (!c) return 1;
+  if (begin_call(c)) return 1;
+  if (nbuf < 0 || (nbuf && (!s2u || !n || !maxbpn || !out || !cap || !sizes))) { c->err = "bad arguments"; return 1; }
+  if (!nbuf) return 0;
+  if (nbuf > 8192) { c->err = "more than 8192 buffers in one call"; return 1; }
+  size_t in_bytes = 0, out_bytes = 0;
+  int nmapped = 0;
+  for (int b = 0; b < nbuf; b++) {
+    if (n[b] < 0 || (n[b] && !s2u[b])) { c->err = "bad buffer"; return 1; }
+    if (maxbpn[b] < 0 || maxbpn[b] > 30) { c->err = "maxbpn out of range (0..30)"; return 1; }
+    if (cap[b] < 0 || (cap[b] && !out[b])) { c->err = "bad output buffer"; return 1; }
+    in_bytes += ((size_t)n[b] * 4 + 255) & ~(size_t)255;
+    out_bytes += ((size_t)cap[b] + 255) & ~(size_t)255;
+    if (used && used[b]) { nmapped++; in_bytes += (2 * 32769 + 255) & ~(size_t)255; }
+  }
+  const size_t need = in_bytes + out_bytes + (size_t)nbuf * (sizeof(BpJob) + sizeof(BpEmit) + sizeof(RcState) + 8 + 256) + (1 << 16);
+  if (arena_reserve(c, need)) return 1;
+  HIPCK(c, hipEventRecord(c->ev0, c->st));
+  std::vector<BpJob> jobs(nbuf);
+  std::vector<BpEmit> emit(nbuf);
+  std::vector<int32_t> which;
+  std::vector<uint8_t *> dout(nbuf, nullptr);
+  RcState *rcs = arena_alloc<RcState>(c, nbuf);
+  if (!rcs) { c->err = "device arena exhausted"; return 1; }
+  for (int b = 0; b < nbuf; b++) {
+    jobs[b].n = n[b]; jobs[b].maxbpn = maxbpn[b]; jobs[b].buf = nullptr;
+    if (n[b] && to_dev(c, s2u[b], (size_t)n[b], &jobs[b].buf)) return 1;
+    emit[b].used = nullptr; emit[b].rc = rcs + b; emit[b].cap = cap[b]; emit[b].pad = 0;
+    if (used && used[b]) {
+      if (to_dev(c, used[b], (size_t)2 * 32769, &emit[b].used)) return 1;
+      which.push_back(b);
+    }
+    dout[b] = (cap[b] && is_device_ptr(out[b])) ? out[b] : arena_alloc<uint8_t>(c, cap[b] ? cap[b] : 1);
+    if (!dout[b]) { c->err = "device arena exhausted"; return 1; }
+    emit[b].out = dout[b];
+  }
+  if (which.empty()) which.push_back(0);
+  BpJob *dj;
+  BpEmit *de;
+  int32_t *dw;
+  if (upload(c, jobs, &dj) || upload(c, emit, &de) || upload(c, which, &dw)) return 1;
+  int32_t *dsz = arena_alloc<int32_t>(c, nbuf);
+  if (!dsz) { c->err = "device arena exhausted"; return 1; }
+  if (sacopt_launch_payloads(dj, de, nbuf, dw, nmapped, c->d_bp_fwd, c->d_bp_inv, c->d_bp_sse, c->bp_tscale, c->bp_xscale, dsz, c->st)) { c->err = "payload kernels: launch failed"; return 1; }
+  HIPCK(c, hipMemcpyAsync(sizes, dsz, (size_t)nbuf * 4, hipMemcpyDeviceToHost, c->st));
+  HIPCK(c, hipStreamSynchronize(c->st));
+  for (int b = 0; b < nbuf; b++) {  // the bytes that were written (a size beyond cap[b] tells the caller its buffer was too small)
+    const size_t got = (size_t)(sizes[b] < cap[b] ? sizes[b] : cap[b]);
+    if (got && dout[b] != out[b]) HIPCK(c, hipMemcpyAsync(out[b], dout[b], got, hipMemcpyDeviceToHost, c->st));
+  }
   return end_timing(c);
 }
 

@@ -62,6 +62,7 @@ def lib():
         L.sacopt_unpredict_stereo_frames.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.sacopt_cost_golomb.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.sacopt_coded_sizes.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.sacopt_encode_payloads.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.sacopt_cost_golomb_noalloc.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.sacopt_cost_meanrms.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.sacopt_lms_pair.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p,
@@ -77,7 +78,7 @@ def lib():
 
 
 EXPORTS = ["sacopt_create", "sacopt_destroy", "sacopt_last_error", "sacopt_probe_rsqrt", "sacopt_base_profile",
-           "sacopt_predict_stereo_frames", "sacopt_set_cost_function", "sacopt_get_costs", "sacopt_recost_last", "sacopt_optimize_frames", "sacopt_encode_frames", "sacopt_encode_frames_selected", "sacopt_unpredict_stereo_frames", "sacopt_cost_golomb", "sacopt_cost_golomb_noalloc", "sacopt_coded_sizes",
+           "sacopt_predict_stereo_frames", "sacopt_set_cost_function", "sacopt_get_costs", "sacopt_recost_last", "sacopt_optimize_frames", "sacopt_encode_frames", "sacopt_encode_frames_selected", "sacopt_unpredict_stereo_frames", "sacopt_cost_golomb", "sacopt_cost_golomb_noalloc", "sacopt_coded_sizes", "sacopt_encode_payloads",
            "sacopt_cost_meanrms", "sacopt_lms_pair", "sacopt_lpc3_pair", "sacopt_rls_run", "sacopt_chol_solve", "sacopt_serial_sum",
            "sacopt_cascade_trace", "sacopt_last_timing"]
 
@@ -368,6 +369,31 @@ class Context:
         out = np.zeros(nb, np.int32)
         self._ck(lib().sacopt_coded_sizes(self._h, nb, ptrs, _p(ns), _p(mb), _p(out)))
         return out
+
+    def encode_payloads(self, bufs, maxbpn, used=None):
+        """sacopt_encode_payloads: the payload bytes of FrameCoder::EncodeMonoFrame_Normal (used[b] None) / _Mapped (used[b] =
+        uint8[2*32769] Remap tables) for numpy int32 s2u buffers. Returns a list of bytes objects."""
+        nb = len(bufs)
+        keep, ptrs, ns = [], (C.c_void_p * max(nb, 1))(), np.zeros(nb, np.int32)
+        uptr, optr = (C.c_void_p * max(nb, 1))(), (C.c_void_p * max(nb, 1))()
+        caps = np.zeros(nb, np.int32)
+        outs = []
+        for i, b in enumerate(bufs):
+            a = np.ascontiguousarray(b, dtype=np.int32); keep.append(a)
+            ptrs[i] = a.ctypes.data if len(a) else None; ns[i] = len(a)
+            u = None if used is None or used[i] is None else np.ascontiguousarray(used[i], dtype=np.uint8)
+            if u is not None:
+                assert len(u) == 2 * 32769
+                keep.append(u)
+            uptr[i] = None if u is None else u.ctypes.data
+            caps[i] = 4 * len(a) + 8192 + 64
+            o = np.zeros(caps[i], np.uint8); outs.append(o)
+            optr[i] = o.ctypes.data
+        mb = np.ascontiguousarray(maxbpn, dtype=np.int32)
+        sizes = np.zeros(nb, np.int32)
+        self._ck(lib().sacopt_encode_payloads(self._h, nb, ptrs, _p(ns), _p(mb), uptr, optr, _p(caps), _p(sizes)))
+        assert (sizes <= caps).all(), "payload larger than its buffer"
+        return [outs[i][:sizes[i]].tobytes() for i in range(nb)]
 
     def cost_meanrms(self, buf):
         buf = np.ascontiguousarray(buf, dtype=np.int32)

@@ -223,6 +223,69 @@ def test_coded_sizes_many_buffers_lane_per_coder_form(oracle):
         assert got[i] == want, (i, len(b), mb[i], got[i], want)
 
 
+def test_encode_payloads_bytes_vs_restated_coder(oracle):
+    # sacopt_encode_payloads = the BYTES of FrameCoder::EncodeMonoFrame_Normal / _Mapped (codec.cpp:237-265) on the device, against
+    # oracle/sac_coder.c (byte-identical to the reference's Encode(): tests/test_oracle_vs_ref.py::test_bitplane_coder_bytes):
+    # three profiles' residuals plain and mapped in one call, a sparse-valued clip (its map pays), silence, a single sample,
+    # lengths around the blocks of 64 decisions, values with bits above the coded planes, an empty buffer
+    import ctypes as C
+    bufs, mb, used = [], [], []
+    for prof, seed, n in ((0, 71, 5000), (1, 72, 3001), (2, 73, 4096)):
+        L, R = stereo_clip(seed, n)
+        if prof == 1:
+            L = (L // 9) * 9; R = (R // 5) * 5
+        r = oracle.predict(prof, L, R, maps=True)
+        for ch, s in enumerate((L, R)):
+            bufs += [r[f"u{ch}"], r[f"m{ch}"]]; mb += [r["maxbpn"][ch], r["maxbpn"][2 + ch]]; used += [None, oracle.remap_tables(s)]
+    rs = np.random.RandomState(3)
+    bufs += [np.zeros(700, np.int32), np.zeros(0, np.int32), np.array([5], np.int32)]; mb += [0, 0, 2]; used += [None, None, None]
+    bufs.append(np.zeros(300, np.int32)); mb.append(0); used.append(oracle.remap_tables(np.zeros(300, np.int32)))   # the map of silence
+    for nb in (63, 64, 65, 129):
+        bufs.append(rs.randint(0, 1 << 9, nb).astype(np.int32)); mb.append(8); used.append(None)
+    for b, m in oracle_lib.out_of_plane_buffers()[:4]:
+        bufs.append(b); mb.append(m); used.append(None)
+    with sacopt.Context(0) as c:
+        got = c.encode_payloads(bufs, mb, used)
+        sizes = c.coded_sizes([b for b, u in zip(bufs, used) if u is None], [m for m, u in zip(mb, used) if u is None])
+    k = 0
+    for i, (b, m, u) in enumerate(zip(bufs, mb, used)):
+        b = np.ascontiguousarray(b, dtype=np.int32)
+        cap = 16 * len(b) + 70000
+        out = np.zeros(cap, np.uint8)
+        if u is None:
+            n = oracle.lib.oracle_encode_mono_normal(b.ctypes.data_as(C.c_void_p), C.c_int(len(b)), C.c_int(int(m)), out.ctypes.data_as(C.c_void_p), C.c_int(cap))
+            assert len(got[i]) == sizes[k]; k += 1
+        else:
+            n = oracle.lib.oracle_encode_mono_mapped(b.ctypes.data_as(C.c_void_p), C.c_int(len(b)), C.c_int(int(m)), u.ctypes.data_as(C.c_void_p),
+                                                     out.ctypes.data_as(C.c_void_p), C.c_int(cap))
+        assert got[i] == out[:n].tobytes(), (i, len(b), m, u is not None, len(got[i]), n)
+
+
+def test_frame_records_from_device_payloads():
+    # the whole encoder on the device: residuals (sacopt_predict_stereo_frames), both payload variants of both channels
+    # (sacopt_encode_payloads), the smaller kept as FrameCoder::EncodeMonoFrame does (codec.cpp:268-280), this repo's container
+    # writer: the frame records are the reference's own Predict() + Encode() + WriteEncoded() bytes
+    if not oracle_lib.have_ref():
+        pytest.skip("oracle/_ref not built")
+    ref = oracle_lib.Ref()
+    o = oracle_lib.Oracle()
+    for prof, (L, R) in ((0, stereo_clip(91, 6000)), (1, stereo_clip(92, 5000)), (2, stereo_clip(93, 4500))):
+        if prof == 1:
+            L = (L // 11) * 11   # a sparse-valued channel: the mapped payload wins
+        want = oracle_lib.ref_encode_frame(ref, prof, L, R)
+        with sacopt.Context(0) as c:   # this host's rsqrtss on both sides
+            r = c.predict(prof, [(L, R)], maps=True)[0]
+            pay = c.encode_payloads([r["u0"], r["m0"], r["u1"], r["m1"]], [r["maxbpn"][0], r["maxbpn"][2], r["maxbpn"][1], r["maxbpn"][3]],
+                                    [None, o.remap_tables(L), None, o.remap_tables(R)])
+        ch = []
+        for k in range(2):
+            plain, mapped = pay[2 * k], pay[2 * k + 1]
+            ch.append((plain, False, int(r["maxbpn"][k])) if len(plain) < len(mapped) else (mapped, True, int(r["maxbpn"][2 + k])))
+        assert sacfile.write_frame(len(L), ch[0], ch[1]) == want, prof
+        if prof == 1:
+            assert ch[0][1]
+
+
 @pytest.mark.parametrize("cost_fn,prof,lens", [(1, 2, [4096, 3000]), (1, 1, [5000]), (2, 2, [4096, 3000]), (2, 0, [2500])])
 def test_optimize_other_cost_functions_vs_oracle(rsqrt_table, oracle, cost_fn, prof, lens):
     # CostFunction is an interface in the reference (codec.h:10-15): Optimize with CostMeanRMS (codec.cpp:302-312; oracle
