@@ -128,6 +128,51 @@ static void predict_batch(std::vector<std::unique_ptr<FrameCoder>> &fc, int nb, 
   }
 }
 
+// SAC_GPU_DEVICE_CODER=1: FrameCoder::Encode (codec.cpp:469-472) of a batch on the device as well -- both payload variants of
+// every channel in ONE sacopt_encode_payloads call, the smaller kept as EncodeMonoFrame does (codec.cpp:268-280). No host coder
+// threads then: the host only reads the WAV and writes the records.
+static void device_encode_batch(std::vector<std::unique_ptr<FrameCoder>> &fc, int nb) {
+  if (!nb) return;
+  const int nbuf = 4 * nb;
+  std::vector<const int32_t *> src(nbuf);
+  std::vector<int32_t> n(nbuf), mb(nbuf), cap(nbuf), sizes(nbuf);
+  std::vector<const uint8_t *> used(nbuf, nullptr);
+  std::vector<std::vector<uint8_t>> tabs((size_t)2 * nb, std::vector<uint8_t>(2 * 32769)), outs(nbuf);
+  std::vector<uint8_t *> out(nbuf);
+  for (int b = 0; b < nb; b++) {
+    FrameCoder &f = *fc[b];
+    for (int ch = 0; ch < 2; ch++) {
+      const int k = 4 * b + 2 * ch;
+      std::vector<uint8_t> &t = tabs[(size_t)2 * b + ch];
+      for (int i = 0; i <= 32768; i++) { t[i] = f.framestats[ch].mymap.usedl[i]; t[32769 + i] = f.framestats[ch].mymap.usedh[i]; }
+      src[k] = &f.s2u_error[ch][0]; mb[k] = f.framestats[ch].maxbpn;
+      src[k + 1] = &f.s2u_error_map[ch][0]; mb[k + 1] = f.framestats[ch].maxbpn_map; used[k + 1] = t.data();
+      for (int v = 0; v < 2; v++) {
+        n[k + v] = f.numsamples;
+        cap[k + v] = 4 * f.numsamples + 8192 + 64;
+        outs[k + v].resize((size_t)cap[k + v]);
+        out[k + v] = outs[k + v].data();
+      }
+    }
+  }
+  if (sacopt_encode_payloads(gpu(), nbuf, src.data(), n.data(), mb.data(), used.data(), out.data(), cap.data(), sizes.data())) {
+    std::cerr << "sacopt_encode_payloads: " << sacopt_last_error(gpu()) << std::endl;
+    exit(2);
+  }
+  for (int b = 0; b < nb; b++) {
+    FrameCoder &f = *fc[b];
+    for (int ch = 0; ch < 2; ch++) {
+      const int k = 4 * b + 2 * ch;
+      if (sizes[k] > cap[k] || sizes[k + 1] > cap[k + 1]) { std::cerr << "payload buffer too small" << std::endl; exit(2); }
+      const bool mapped = !(sizes[k] < sizes[k + 1]);  // codec.cpp:272-279
+      const int pick = k + (mapped ? 1 : 0);
+      f.framestats[ch].enc_mapped = mapped;
+      f.encoded[ch].Reset();
+      for (int i = 0; i < sizes[pick]; i++) f.encoded[ch].PutByte(outs[pick][(size_t)i]);
+    }
+  }
+}
+
 void Codec::EncodeFile(Wav &myWav, Sac &mySac, int profile) {
   const int numchannels = myWav.getNumChannels();
   framesize = 4 * myWav.getSampleRate();
@@ -156,6 +201,7 @@ void Codec::EncodeFile(Wav &myWav, Sac &mySac, int profile) {
   auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
   gpu();  // context creation (rsqrtss probe, streams) is not part of the loop's time
   const bool optimize = getenv("SAC_GPU_OPTIMIZE") != nullptr;
+  const bool device_coder = getenv("SAC_GPU_DEVICE_CODER") != nullptr;
   std::vector<std::unique_ptr<FrameCoder>> set[2];
   for (auto &s : set) for (int b = 0; b < B; b++) s.emplace_back(new FrameCoder(numchannels, framesize, profile));
   int nb[2] = {0, 0};
@@ -198,6 +244,17 @@ void Codec::EncodeFile(Wav &myWav, Sac &mySac, int profile) {
     }
     const auto a = clk::now();
     predict_batch(set[cur], nb[cur], optimize);  // GPU (blocking); the coder threads of the previous batch run meanwhile
+    if (device_coder) {  // ... or no host coder at all: the payloads come from the device too, the records go out at once
+      device_encode_batch(set[cur], nb[cur]);
+      gpu_s += secs(a, clk::now());
+      batches++;
+      for (int b = 0; b < nb[cur]; b++) {
+        set[cur][b]->WriteEncoded(mySac);
+        samplescoded += set[cur][b]->GetNumSamples();
+      }
+      PrintProgress(samplescoded, myWav.getNumSamples());
+      continue;
+    }
     gpu_s += secs(a, clk::now());
     batches++;
     if (pending) finish_coding(cur ^ 1);
@@ -209,6 +266,6 @@ void Codec::EncodeFile(Wav &myWav, Sac &mySac, int profile) {
   std::cout << std::endl;
   const double total = secs(t_begin, clk::now());
   std::cerr << "sac_gpu_timing {\"samples\": " << myWav.getNumSamples() << ", \"batch_frames\": " << B << ", \"batches\": " << batches
-            << ", \"coder_threads\": " << T << ", \"optimize\": " << (optimize ? 1 : 0) << ", \"loop_s\": " << total << ", \"gpu_calls_s\": " << gpu_s
+            << ", \"coder_threads\": " << (device_coder ? 0 : T) << ", \"device_coder\": " << (device_coder ? 1 : 0) << ", \"optimize\": " << (optimize ? 1 : 0) << ", \"loop_s\": " << total << ", \"gpu_calls_s\": " << gpu_s
             << ", \"coder_critical_path_s\": " << coder_crit_s << "}" << std::endl;
 }

@@ -15,8 +15,10 @@ FRAME = 176400
 REF = os.path.join(ROOT, "oracle", "_ref")
 
 
-def run_gpu(wav, sac, batch, threads):
+def run_gpu(wav, sac, batch, threads, device_coder=False):
     env = dict(os.environ, SAC_GPU_BATCH=str(batch), SAC_GPU_CODER_THREADS=str(threads), SAC_GPU_OPTIMIZE="1")
+    if device_coder:
+        env["SAC_GPU_DEVICE_CODER"] = "1"   # FrameCoder::Encode on the device too (sacopt_encode_payloads): no host coder
     t0 = time.perf_counter()
     out = subprocess.run([os.path.join(REF, "sac_gpu"), "--encode", "--high", wav, sac], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
                          text=True, env=env, timeout=600)
@@ -45,6 +47,12 @@ def main():
             open(wav, "wb").write(wav_bytes(L[:nfr * FRAME], R[:nfr * FRAME], 44100))
             run_gpu(wav, os.path.join(td, name + ".sac"), batch, threads)            # warm-up (page cache, GPU code upload)
             res[name] = run_gpu(wav, os.path.join(td, name + ".sac"), batch, threads)
+        # the whole encoder on the device: payload bytes from sacopt_encode_payloads, 75 frames per call; the file must be the same file
+        name = "track_300s"
+        wav = os.path.join(td, name + ".wav")
+        run_gpu(wav, os.path.join(td, "dev.sac"), 75, threads, device_coder=True)
+        res["track_300s_device_coder"] = run_gpu(wav, os.path.join(td, "dev.sac"), 75, threads, device_coder=True)
+        res["track_300s_device_coder"]["same_file_as_host_coder"] = open(os.path.join(td, "dev.sac"), "rb").read() == open(os.path.join(td, name + ".sac"), "rb").read()
         # identity with the reference binary's own file, on a prefix it codes in a few seconds (2 frames, batches of 1 frame)
         wav = os.path.join(td, "prefix.wav")
         open(wav, "wb").write(wav_bytes(L[:2 * FRAME], R[:2 * FRAME], 44100))
