@@ -6,6 +6,7 @@ edge of the kernels (8, 32, 64, 256, 512, 2048, 4096, 7056, 16384) and random on
   unpredict plain residuals, and mapped ones with the tables of Remap::Analyse      == oracle and == the input samples
   optimize  a few short clips, random number of optimised coefficients                == oracle: winners and cost trace
   coded sizes of the plain and mapped s2u buffers of every clip                       == oracle coder's byte counts
+  payload bytes of both variants (sacopt_encode_payloads) of every third clip         == oracle coder's bytes
   get_costs on random windows with carried state, cost_golomb / _noalloc / cost_meanrms on raw buffers, the decoder on
   residuals no encoder wrote (clamp, Unmap tables), encode in both modes and Optimize with the other two cost functions
 usage: fuzz_parity.py [seed] [rounds] [clips per round] [full-size frames]      (test infrastructure: it uses the oracle)"""
@@ -126,6 +127,25 @@ def fuzz(ctx, orc, seed, rounds, nclips, nbig=0, log=print):
             got = ctx.coded_sizes(bufs, mb)
             for j in range(len(bufs)):
                 check(int(got[j]) == coder_size(bufs[j], mb[j]), "coded size", prof, j // 4, j % 4, len(bufs[j]), mb[j])
+            # the payload BYTES of both variants (EncodeMonoFrame_Normal / _Mapped) for a third of the clips
+            pj = [i for i in range(nclips) if i % 3 == 0 and lens[i] <= 20000]
+            pb, pm_, pu = [], [], []
+            for i in pj:
+                r = refs[i]
+                for chn, src in enumerate(clips[i]):
+                    pb += [r[f"u{chn}"], r[f"m{chn}"]]; pm_ += [int(r["maxbpn"][chn]), int(r["maxbpn"][2 + chn])]; pu += [None, orc.remap_tables(src)]
+            if pb:
+                pay = ctx.encode_payloads(pb, pm_, pu)
+                for j, (b_, m_, u_) in enumerate(zip(pb, pm_, pu)):
+                    b_ = np.ascontiguousarray(b_, dtype=np.int32)
+                    cap_ = 16 * len(b_) + 70000
+                    o_ = np.zeros(cap_, np.uint8)
+                    if u_ is None:
+                        n_ = orc.lib.oracle_encode_mono_normal(b_.ctypes.data_as(C.c_void_p), C.c_int(len(b_)), C.c_int(m_), o_.ctypes.data_as(C.c_void_p), C.c_int(cap_))
+                    else:
+                        n_ = orc.lib.oracle_encode_mono_mapped(b_.ctypes.data_as(C.c_void_p), C.c_int(len(b_)), C.c_int(m_), u_.ctypes.data_as(C.c_void_p),
+                                                               o_.ctypes.data_as(C.c_void_p), C.c_int(cap_))
+                    check(pay[j] == o_[:n_].tobytes(), "payload bytes", prof, pj[j // 4], j % 4, len(b_), m_, len(pay[j]), n_)
             # optimizer: a few short clips in one call
             pick = [i for i in range(nclips) if 64 <= lens[i] <= 6000][:4]
             if pick:
