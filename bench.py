@@ -161,6 +161,36 @@ def two_channel_extra(ctx, torch, dev, stereo_clip, sacopt, nch=L1C_FRAMES + 1, 
             "kernel_ms": t["lms_ms"], "cycles_per_sample_at_2.4GHz": t["lms_ms"] * 2.4e6 / per_chain if per_chain else None}
 
 
+def device_coder_extra(ctx, torch, sacopt, b, nfr, step_s):
+    """Not the headline: FrameCoder::Encode of the clip on the device as well (sacopt_encode_payloads, SURVEY 8f.4 taken to the
+    bytes): both payload variants of every channel from the residuals the step left in HBM, the smaller kept as EncodeMonoFrame
+    does. Bytes are checked against the oracle's coder in tests/; here the kept sizes are compared with the host coder's."""
+    L = b["dL"].cpu().numpy(); R = b["dR"].cpu().numpy()
+
+    def tables(x):   # Remap::Analyse (map.cpp:111-130): usedl[0..32768] then usedh[0..32768]
+        t = np.zeros(2 * 32769, np.uint8)
+        t[32769 + x[(x > 0) & (x <= 32768)]] = 1
+        t[-x[(x < 0) & (x >= -32768)]] = 1
+        return t
+    bufs, mb, used = [], [], []
+    for f in range(nfr):
+        o = b["outs"][f]
+        for ch, x in enumerate((L, R)):
+            u = tables(x[f * FRAME:(f + 1) * FRAME])
+            bufs += [(o[f"u{ch}"], FRAME), (o[f"m{ch}"], FRAME)]
+            mb += [int(b["maxbpn"][f][ch]), int(b["maxbpn"][f][2 + ch])]
+            used += [None, u]
+    ctx.encode_payloads(bufs[:4], mb[:4], used[:4])   # warm-up (arena)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pay = ctx.encode_payloads(bufs, mb, used)
+    dt = time.perf_counter() - t0
+    kept = sum(min(len(pay[k]), len(pay[k + 1])) for k in range(0, len(pay), 2))
+    return {"workload": f"both payload variants of both channels of {nfr} frames x {FRAME} ({len(bufs)} coders, one call)", "ms": 1e3 * dt,
+            "kept_payload_bytes": kept, "mapped_kept": sum(len(pay[k + 1]) <= len(pay[k]) for k in range(0, len(pay), 2)),
+            "all_device_samples_per_s": nfr * FRAME / (step_s + dt), "note": "GPU step, then the coder, nothing on the host but the container"}
+
+
 def apply_params_extra(ctx, torch, sacopt, b, nfr):
     """Not the headline: SURVEY §8f.2's opt-in mode, where the stream is coded with the parameters Optimize selected: the
     full-frame pass depends on the optimizer's result. As two library calls (nothing overlaps) and as ONE
@@ -417,6 +447,9 @@ def main():
             line["apply_selected_parameters"] = apply_params_extra(ctx, torch, sacopt, b, nfr)
         if world == 1 and nfr == NFRAMES and not args.no_extras:
             line["two_channel_kernel"] = two_channel_extra(ctx, torch, dev, stereo_clip, sacopt)
+        if world == 1 and nfr == NFRAMES and not args.no_extras and "maxbpn" in b:
+            ctx.encode(sacopt.PROFILE_HIGH, frames, device_out=outs)   # residuals of the clip back in the output buffers
+            line["device_coder"] = device_coder_extra(ctx, torch, sacopt, b, nfr, dt / args.steps)
         if not args.no_large_batch and world == 1 and nfr == NFRAMES:
             line["large_batch"] = large_batch_extra(ctx, torch, dev, stereo_clip, sacopt)   # untimed extra, not `value`
         if not args.no_decode and world == 1:

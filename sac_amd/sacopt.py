@@ -372,15 +372,19 @@ class Context:
 
     def encode_payloads(self, bufs, maxbpn, used=None):
         """sacopt_encode_payloads: the payload bytes of FrameCoder::EncodeMonoFrame_Normal (used[b] None) / _Mapped (used[b] =
-        uint8[2*32769] Remap tables) for numpy int32 s2u buffers. Returns a list of bytes objects."""
+        uint8[2*32769] Remap tables) for s2u buffers (numpy int32 arrays or (device pointer, n) tuples). Returns a list of bytes objects."""
         nb = len(bufs)
         keep, ptrs, ns = [], (C.c_void_p * max(nb, 1))(), np.zeros(nb, np.int32)
         uptr, optr = (C.c_void_p * max(nb, 1))(), (C.c_void_p * max(nb, 1))()
         caps = np.zeros(nb, np.int32)
         outs = []
         for i, b in enumerate(bufs):
-            a = np.ascontiguousarray(b, dtype=np.int32); keep.append(a)
-            ptrs[i] = a.ctypes.data if len(a) else None; ns[i] = len(a)
+            if isinstance(b, np.ndarray):
+                a = np.ascontiguousarray(b, dtype=np.int32); keep.append(a)
+                ptrs[i] = a.ctypes.data if len(a) else None; ns[i] = len(a)
+            else:   # (device pointer, n)
+                a = range(int(b[1]))
+                ptrs[i] = int(b[0]); ns[i] = int(b[1])
             u = None if used is None or used[i] is None else np.ascontiguousarray(used[i], dtype=np.uint8)
             if u is not None:
                 assert len(u) == 2 * 32769
