@@ -122,6 +122,49 @@ class FrameCoder {
       for (int i = 0; i < ncoef; i++) f.optprofile.coefs[i].vdef = best[(size_t)b * ncoef + i];
     }
   }
+  // FrameCoder::Encode (codec.cpp:469-472) of a batch ON THE DEVICE: both payload variants of both channels of every frame in one
+  // sacopt_encode_payloads call (EncodeMonoFrame_Normal / _Mapped, codec.cpp:237-265), the mapped one kept unless the plain one is
+  // strictly smaller (codec.cpp:268-280). Fills recs[b].ch[c] (payload, enc_mapped, maxbpn) and enc_mapped[c]; needs the
+  // residuals of PredictBatch*. The host's own coder is the alternative: this pays for large batches.
+  static void EncodeBatchOn(sacopt_ctx *ctx, FrameCoder *const *fc, int nframes, FrameRecord *recs) {
+    if (nframes <= 0) return;
+    const int nbuf = 4 * nframes;
+    std::vector<const int32_t *> src(nbuf);
+    std::vector<int32_t> n(nbuf), mb(nbuf), cap(nbuf), sizes(nbuf);
+    std::vector<const uint8_t *> used(nbuf, nullptr);
+    std::vector<std::vector<uint8_t>> tabs((size_t)2 * nframes), outs(nbuf);
+    std::vector<uint8_t *> out(nbuf);
+    for (int b = 0; b < nframes; b++) {
+      FrameCoder &f = *fc[b];
+      for (int ch = 0; ch < 2; ch++) {
+        const int k = 4 * b + 2 * ch;
+        tabs[(size_t)2 * b + ch] = AnalyseUsed(f.samples[ch].data(), f.numsamples);
+        src[k] = f.s2u_error[ch].data(); mb[k] = f.maxbpn[ch];
+        src[k + 1] = f.s2u_error_map[ch].data(); mb[k + 1] = f.maxbpn_map[ch]; used[k + 1] = tabs[(size_t)2 * b + ch].data();
+        for (int v = 0; v < 2; v++) {
+          n[k + v] = f.numsamples;
+          cap[k + v] = 4 * f.numsamples + 8192 + 64;
+          outs[k + v].resize((size_t)cap[k + v]);
+          out[k + v] = outs[k + v].data();
+        }
+      }
+    }
+    check_on(ctx, sacopt_encode_payloads(ctx, nbuf, src.data(), n.data(), mb.data(), used.data(), out.data(), cap.data(), sizes.data()));
+    for (int b = 0; b < nframes; b++) {
+      FrameCoder &f = *fc[b];
+      recs[b].numsamples = (uint32_t)f.numsamples;
+      for (int ch = 0; ch < 2; ch++) {
+        const int k = 4 * b + 2 * ch;
+        if (sizes[k] > cap[k] || sizes[k + 1] > cap[k + 1]) throw std::runtime_error("sacopt: payload buffer too small");
+        const bool mapped = !(sizes[k] < sizes[k + 1]);
+        const int pick = k + (mapped ? 1 : 0);
+        f.enc_mapped[ch] = mapped;
+        recs[b].ch[ch].enc_mapped = mapped;
+        recs[b].ch[ch].maxbpn = mapped ? f.maxbpn_map[ch] : f.maxbpn[ch];
+        recs[b].ch[ch].payload.assign(outs[pick].begin(), outs[pick].begin() + sizes[pick]);
+      }
+    }
+  }
   // Per-frame stream fields of the parameter extension (sacfile.h): the frame's optprofile values; minval / maxval are
   // written as the full int32 range, which makes StereoHigh::Unpredict's clamp (profile.cpp:163,170) the identity -- the
   // encoder does not clamp (profile.cpp:152,156), so anything narrower would not round-trip.

@@ -129,6 +129,9 @@ int main(int argc, char **argv) {
           apply_ok = apply_ok && dc[b]->samples[0] == fc[b]->samples[0] && dc[b]->samples[1] == fc[b]->samples[1] && pos == stream.size();
       }
     }
+    // FrameCoder::Encode on the device (EncodeBatchOn): the frame records of the stream the reference would write
+    std::vector<sacopt::FrameRecord> recs((size_t)nframes);
+    sacopt::FrameCoder::EncodeBatchOn(ctx, ptr.data(), nframes, recs.data());
     for (int b = 0; b < nframes; b++) {
       sacopt::FrameCoder &f = *fc[b];
       printf("frame %d in %016" PRIx64 " %016" PRIx64 " err %016" PRIx64 " %016" PRIx64 " s2u %016" PRIx64 " %016" PRIx64
@@ -139,6 +142,11 @@ int main(int argc, char **argv) {
       for (auto &c : f.optprofile.coefs) printf(" %.17g", c.vdef);
       printf(" decode %s", dec_ok[b] ? "ok" : "MISMATCH");
       if (apply_ok >= 0) printf(" apply %s", apply_ok ? "ok" : "MISMATCH");
+      std::vector<uint8_t> rec;
+      sacopt::WriteEncoded(rec, recs[(size_t)b], false);
+      uint64_t h = 1469598103934665603ull;
+      for (uint8_t v : rec) h = (h ^ v) * 1099511628211ull;
+      printf(" record %zu %016" PRIx64 " mapped %d %d", rec.size(), h, (int)recs[(size_t)b].ch[0].enc_mapped, (int)recs[(size_t)b].ch[1].enc_mapped);
       printf("\n");
     }
   } catch (const std::exception &e) {

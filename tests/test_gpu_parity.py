@@ -450,6 +450,20 @@ def test_cpp_host_framecoder():
         assert same_bits(np.array([float(x) for x in ln[20:28]]), best[b])
         assert ln[28:30] == ["decode", "ok"]  # FrameCoder::Unpredict of the C++ mirror (one channel mapped) restores the samples
         assert ln[30:32] == ["apply", "ok"]   # frames coded with the SELECTED parameters, carried by sacfile.h's extension records, decode back
+        # FrameCoder::EncodeBatchOn + sacfile.h's WriteEncoded: the frame record, against the ctypes path + the python container writer
+        import oracle_lib
+        from sac_amd import sacfile
+        orc = oracle_lib.Oracle()
+        with sacopt.Context(0) as c2:
+            pay = c2.encode_payloads([o["u0"], o["m0"], o["u1"], o["m1"]], [o["maxbpn"][0], o["maxbpn"][2], o["maxbpn"][1], o["maxbpn"][3]],
+                                     [None, orc.remap_tables(L), None, orc.remap_tables(R)])
+        ch = [(pay[2 * k], False, int(o["maxbpn"][k])) if len(pay[2 * k]) < len(pay[2 * k + 1]) else (pay[2 * k + 1], True, int(o["maxbpn"][2 + k])) for k in range(2)]
+        rec = np.frombuffer(sacfile.write_frame(n, ch[0], ch[1]), np.uint8)
+        hsh = 1469598103934665603
+        for v in rec.tolist():
+            hsh = ((hsh ^ v) * 1099511628211) & 0xffffffffffffffff
+        assert ln[32] == "record" and int(ln[33]) == len(rec) and int(ln[34], 16) == hsh
+        assert [int(x) for x in ln[36:38]] == [int(ch[0][1]), int(ch[1][1])]
 
 
 def test_cpp_host_sharder_two_contexts_two_threads():
@@ -465,7 +479,7 @@ def test_cpp_host_sharder_two_contexts_two_threads():
         out = subprocess.run([exe, "2", "5", "2600", "2", str(nctx)], capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stderr
         runs[nctx] = out.stdout.strip().splitlines()
-    assert len(runs[1]) == 5 and all(ln.endswith("decode ok apply ok") for ln in runs[1])
+    assert len(runs[1]) == 5 and all(" decode ok apply ok record " in ln for ln in runs[1])
     assert runs[2] == runs[1] and runs[3] == runs[1]
 
 
