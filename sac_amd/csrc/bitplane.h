@@ -347,44 +347,49 @@ __device__ __forceinline__ int bpp_clamp(int v, int lo, int hi) { return max(lo,
 #endif
 #define BPP_B 64
 #define BPP_RING 8
-#define BPP_NCOD 2
+// coders per workgroup (NCOD): 2 share the 74 KB of tables (512 coders in flight on the chip), 1 has its CU to itself and is
+// 15 % faster (570 against 670 cycles per decision: 60 full-frame buffers 830 against 980 ms) -- taken when the call's buffers
+// fit the chip one per CU
+#ifndef BPP_ONE_MAX
+#define BPP_ONE_MAX 256
+#endif
 #define BPP_STAGES 5
-#define BPP_NT (BPP_NCOD * BPP_STAGES * 64)
 #define BPP_SSE (32 * 2 * 33)
 // EMIT: also write the bytes (stage S4: RangeCoderSH::ShiftLow's cache / carry / 0xFF-run logic, range.cpp:80-90, one byte store
 // by lane 0 per output byte), starting from the state k_mapenc left when the buffer is coded with its map in front.
-template <bool EMIT>
-__global__ __launch_bounds__(BPP_NT) void k_bppipe(const BpJob *__restrict__ jobs, int nbuf, BpTables tb, int32_t *__restrict__ sizes, const BpEmit *__restrict__ emit) {
+template <bool EMIT, int NCOD>
+__global__ __launch_bounds__(NCOD * BPP_STAGES * 64) void k_bppipe(const BpJob *__restrict__ jobs, int nbuf, BpTables tb, int32_t *__restrict__ sizes, const BpEmit *__restrict__ emit) {
+  constexpr int NT = NCOD * BPP_STAGES * 64;
   __shared__ int16_t fwd[BP_PSCALE];
   __shared__ uint16_t inv[(1 << BP_DBITS) + 2];  // [0] = 0 and [4097] = PSCALE - 1: LogDomain::Inv beyond its table (domain.h:33-38)
   __shared__ uint16_t divt[BP_DIVN];
   __shared__ uint16_t sinit[BP_SSE_N + 1];
-  __shared__ uint32_t rec[BPP_NCOD][BPP_RING][BPP_B];
-  __shared__ uint16_t pcs[BPP_NCOD][BPP_RING][4][BPP_B];  // (row 3: where the lanes without a counter store)
-  __shared__ uint16_t pds[BPP_NCOD][BPP_RING][BPP_B], pss[BPP_NCOD][BPP_RING][BPP_B];
-  __shared__ uint16_t c1[BPP_NCOD][BP_NC1], c2[BPP_NCOD][BP_NC2];
-  __shared__ int wts[BPP_NCOD][48];  // lmixref[8][3], lmixsig[8][2 + one weight that stays 0 (its input is 0)]
-  __shared__ uint32_t ssel[BPP_NCOD][BPP_SSE];  // [(msb * 2 + lb) * 33 + q]: p1 | counter << 16
-  __shared__ int32_t tile[BPP_NCOD][BPP_B + 8];
+  __shared__ uint32_t rec[NCOD][BPP_RING][BPP_B];
+  __shared__ uint16_t pcs[NCOD][BPP_RING][4][BPP_B];  // (row 3: where the lanes without a counter store)
+  __shared__ uint16_t pds[NCOD][BPP_RING][BPP_B], pss[NCOD][BPP_RING][BPP_B];
+  __shared__ uint16_t c1[NCOD][BP_NC1], c2[NCOD][BP_NC2];
+  __shared__ int wts[NCOD][48];  // lmixref[8][3], lmixsig[8][2 + one weight that stays 0 (its input is 0)]
+  __shared__ uint32_t ssel[NCOD][BPP_SSE];  // [(msb * 2 + lb) * 33 + q]: p1 | counter << 16
+  __shared__ int32_t tile[NCOD][BPP_B + 8];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int cod = wave / BPP_STAGES, stage = wave - cod * BPP_STAGES;
-  const int b = blockIdx.x * BPP_NCOD + cod;
+  const int b = blockIdx.x * NCOD + cod;
   const bool live = b < nbuf;
-  for (int i = tid; i < BP_PSCALE; i += BPP_NT) fwd[i] = tb.fwd[i];
-  for (int i = tid; i < (1 << BP_DBITS); i += BPP_NT) inv[i + 1] = tb.inv[i];
+  for (int i = tid; i < BP_PSCALE; i += NT) fwd[i] = tb.fwd[i];
+  for (int i = tid; i < (1 << BP_DBITS); i += NT) inv[i + 1] = tb.inv[i];
   if (tid == 0) { inv[0] = 0; inv[(1 << BP_DBITS) + 1] = BP_PSCALE - 1; }
-  for (int i = tid; i < BP_DIVN; i += BPP_NT) divt[i] = (uint16_t)(BP_PSCALE / (i + 3));  // counter.h:38-50
+  for (int i = tid; i < BP_DIVN; i += NT) divt[i] = (uint16_t)(BP_PSCALE / (i + 3));  // counter.h:38-50
   if (tid <= BP_SSE_N) sinit[tid] = tb.sse_init[tid];
-  for (int i = tid; i < BPP_NCOD * BP_NC1; i += BPP_NT) (&c1[0][0])[i] = BP_PSCALE >> 1;
-  for (int i = tid; i < BPP_NCOD * BP_NC2; i += BPP_NT) (&c2[0][0])[i] = BP_PSCALE >> 1;
-  for (int i = tid; i < BPP_NCOD * 48; i += BPP_NT) (&wts[0][0])[i] = 0;  // NMixLogistic::Init(0)
+  for (int i = tid; i < NCOD * BP_NC1; i += NT) (&c1[0][0])[i] = BP_PSCALE >> 1;
+  for (int i = tid; i < NCOD * BP_NC2; i += NT) (&c2[0][0])[i] = BP_PSCALE >> 1;
+  for (int i = tid; i < NCOD * 48; i += NT) (&wts[0][0])[i] = 0;  // NMixLogistic::Init(0)
   const int n = live ? jobs[b].n : 0, mbp = live ? jobs[b].maxbpn : -1;
   const int32_t *buf = live ? jobs[b].buf : nullptr;
   const int nb = (n + BPP_B - 1) / BPP_B;
   const int nblk = (n > 0 && mbp >= 0) ? (mbp + 1) * nb : 0;
   int nblk_max = 0;  // (the loop holds workgroup barriers: its bound is the same in every wave)
-  for (int k = 0; k < BPP_NCOD; k++) {
-    const int bb = blockIdx.x * BPP_NCOD + k;
+  for (int k = 0; k < NCOD; k++) {
+    const int bb = blockIdx.x * NCOD + k;
     if (bb < nbuf) {
       const int nn = jobs[bb].n, mm = jobs[bb].maxbpn;
       const int q = (nn > 0 && mm >= 0) ? (mm + 1) * ((nn + BPP_B - 1) / BPP_B) : 0;

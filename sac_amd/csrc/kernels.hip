@@ -2370,7 +2370,8 @@ extern "C" int sacopt_launch_bpsize(const BpJob *jobs, int nbuf, int maxn, int m
   // the stage-pipeline form (bitplane.h): up to 16 workgroup rounds of two coders per CU; beyond that the lane-per-coder forms
   // move more decisions per CU
   if (BP_PIPE && nbuf <= BP_PIPE_MAX) {
-    hipLaunchKernelGGL(k_bppipe<false>, dim3((nbuf + BPP_NCOD - 1) / BPP_NCOD), dim3(BPP_NT), 0, st, jobs, nbuf, tbp, sizes, (const BpEmit *)nullptr);
+    if (nbuf <= BPP_ONE_MAX) hipLaunchKernelGGL((k_bppipe<false, 1>), dim3(nbuf), dim3(BPP_STAGES * 64), 0, st, jobs, nbuf, tbp, sizes, (const BpEmit *)nullptr);
+    else hipLaunchKernelGGL((k_bppipe<false, 2>), dim3((nbuf + 1) / 2), dim3(2 * BPP_STAGES * 64), 0, st, jobs, nbuf, tbp, sizes, (const BpEmit *)nullptr);
     return hipGetLastError() != hipSuccess;
   }
   const int nblk = (nbuf + 63) / 64;
@@ -2392,7 +2393,8 @@ extern "C" int sacopt_launch_payloads(const BpJob *jobs, const BpEmit *emit, int
   if (nbuf > BP_PIPE_MAX) return 1;
   BpTables tbp = {fwd, inv, sse_init, tscale, xscale};
   if (nmapped > 0) hipLaunchKernelGGL(k_mapenc, dim3(nmapped), dim3(64), 0, st, emit, which, tbp);
-  hipLaunchKernelGGL(k_bppipe<true>, dim3((nbuf + BPP_NCOD - 1) / BPP_NCOD), dim3(BPP_NT), 0, st, jobs, nbuf, tbp, sizes, emit);
+  if (nbuf <= BPP_ONE_MAX) hipLaunchKernelGGL((k_bppipe<true, 1>), dim3(nbuf), dim3(BPP_STAGES * 64), 0, st, jobs, nbuf, tbp, sizes, emit);
+  else hipLaunchKernelGGL((k_bppipe<true, 2>), dim3((nbuf + 1) / 2), dim3(2 * BPP_STAGES * 64), 0, st, jobs, nbuf, tbp, sizes, emit);
   return hipGetLastError() != hipSuccess;
 }
 extern "C" int sacopt_launch_map(const MapJob *jobs, int njobs, int max_numsamples, int max_n, hipStream_t st) {
