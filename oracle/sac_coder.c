@@ -2,8 +2,8 @@
  *
  * Plain-C restatement of sac's bit-plane context-mixing coder (autch/sac v0.0.4), the host-side step that follows the
  * optimizer / predictor path: SURVEY.md 8f.4 ("bit-plane coder cost"). It exists to say what a frame COSTS in bytes for a
- * given parameter set without the reference (tools/coded_bytes.py), and as the specification of a future device kernel
- * that would make the coded size the optimizer's objective. Every function cites the reference file:line it follows
+ * given parameter set without the reference (tools/coded_bytes.py), and as the checker of the device kernels that compute
+ * the coded size (the optimizer's other objective) and the payload bytes (sac_amd/csrc/bitplane.h). Every function cites the reference file:line it follows
  * (paths relative to /root/reference). Pinned byte for byte against the reference's own Encode() in
  * tests/test_oracle_vs_ref.py::test_bitplane_coder_bytes.
  */
