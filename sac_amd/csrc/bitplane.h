@@ -328,7 +328,7 @@ __global__ __launch_bounds__(WPC ? 64 * LPW : 64) void k_bpsize(const BpJob *__r
 //   S4  final mixer + RangeCoderSH byte count
 // Iteration `it` of the workgroup loop: stage i works on block it - i, one workgroup barrier per iteration; the hand-over
 // buffers are rings of 8 blocks in LDS. The time per decision is the slowest stage's chain (~300 cycles) instead of the sum.
-// Two coders per workgroup share the 74 KB of tables (10 waves, one workgroup per CU: 512 coders in flight on the chip).
+// One or two coders per workgroup (NCOD below); the 64 KB stretch table is read from global memory (BPP_FWD_LDS).
 // Same integer arithmetic, same order of updates per counter / weight / bin: sizes identical to k_bpsize.
 // branch-free forms of the rounding shifts and clamps (the values of the serial loops are wave-uniform: the compiler keeps them in
 // scalar registers and turned every `x < 0 ? .. : ..` into a scalar branch, ~25 cycles each, twenty per decision)
@@ -347,11 +347,12 @@ __device__ __forceinline__ int bpp_clamp(int v, int lo, int hi) { return max(lo,
 #endif
 #define BPP_B 64
 #define BPP_RING 8
-// coders per workgroup (NCOD): 2 share the 74 KB of tables (512 coders in flight on the chip), 1 has its CU to itself and is
-// 15 % faster (570 against 670 cycles per decision: 60 full-frame buffers 830 against 980 ms) -- taken when the call's buffers
-// fit the chip one per CU
+// coders per workgroup (NCOD): 1 (5 waves, 28 KB of LDS: five workgroups fit a CU) for calls of up to 1280 buffers -- a coder
+// that has its CU to itself needs 570 cycles per decision against 670 when two share one (60 full-frame buffers 830 against
+// 980 ms), and two workgroups of one coder are never slower than one workgroup of two (an optimizer round's 360 buffers 87
+// against 105 ms, 720 buffers 118 against 158 ms); 2 (10 waves, 45 KB) beyond.
 #ifndef BPP_ONE_MAX
-#define BPP_ONE_MAX 256
+#define BPP_ONE_MAX 1280
 #endif
 #define BPP_STAGES 5
 #define BPP_SSE (32 * 2 * 33)
@@ -360,7 +361,11 @@ __device__ __forceinline__ int bpp_clamp(int v, int lo, int hi) { return max(lo,
 template <bool EMIT, int NCOD>
 __global__ __launch_bounds__(NCOD * BPP_STAGES * 64) void k_bppipe(const BpJob *__restrict__ jobs, int nbuf, BpTables tb, int32_t *__restrict__ sizes, const BpEmit *__restrict__ emit) {
   constexpr int NT = NCOD * BPP_STAGES * 64;
-  __shared__ int16_t fwd[BP_PSCALE];
+#ifndef BPP_FWD_LDS
+#define BPP_FWD_LDS 0  // 1: the stretch table (64 KB) in LDS as well. Every read of it is in a stage's vector prologue (a lane per decision,
+#endif                 // 64 at once), off the serial chains: from global memory (L2) the stages are as fast and the workgroup needs 45 KB less
+  __shared__ int16_t fwd_l[BPP_FWD_LDS ? BP_PSCALE : 1];
+  const int16_t *const fwd = BPP_FWD_LDS ? fwd_l : tb.fwd;
   __shared__ uint16_t inv[(1 << BP_DBITS) + 2];  // [0] = 0 and [4097] = PSCALE - 1: LogDomain::Inv beyond its table (domain.h:33-38)
   __shared__ uint16_t divt[BP_DIVN];
   __shared__ uint16_t sinit[BP_SSE_N + 1];
@@ -375,7 +380,7 @@ __global__ __launch_bounds__(NCOD * BPP_STAGES * 64) void k_bppipe(const BpJob *
   const int cod = wave / BPP_STAGES, stage = wave - cod * BPP_STAGES;
   const int b = blockIdx.x * NCOD + cod;
   const bool live = b < nbuf;
-  for (int i = tid; i < BP_PSCALE; i += NT) fwd[i] = tb.fwd[i];
+  if (BPP_FWD_LDS) for (int i = tid; i < BP_PSCALE; i += NT) fwd_l[i] = tb.fwd[i];
   for (int i = tid; i < (1 << BP_DBITS); i += NT) inv[i + 1] = tb.inv[i];
   if (tid == 0) { inv[0] = 0; inv[(1 << BP_DBITS) + 1] = BP_PSCALE - 1; }
   for (int i = tid; i < BP_DIVN; i += NT) divt[i] = (uint16_t)(BP_PSCALE / (i + 3));  // counter.h:38-50
