@@ -159,11 +159,20 @@ static void device_encode_batch(std::vector<std::unique_ptr<FrameCoder>> &fc, in
     std::cerr << "sacopt_encode_payloads: " << sacopt_last_error(gpu()) << std::endl;
     exit(2);
   }
+  for (int k = 0; k < nbuf; k++)  // incompressible data can need more than 4 bytes per sample: that buffer again, with the size the call reported
+    if (sizes[k] > cap[k]) {
+      cap[k] = sizes[k];
+      outs[k].resize((size_t)cap[k]);
+      out[k] = outs[k].data();
+      if (sacopt_encode_payloads(gpu(), 1, &src[k], &n[k], &mb[k], &used[k], &out[k], &cap[k], &sizes[k])) {
+        std::cerr << "sacopt_encode_payloads: " << sacopt_last_error(gpu()) << std::endl;
+        exit(2);
+      }
+    }
   for (int b = 0; b < nb; b++) {
     FrameCoder &f = *fc[b];
     for (int ch = 0; ch < 2; ch++) {
       const int k = 4 * b + 2 * ch;
-      if (sizes[k] > cap[k] || sizes[k + 1] > cap[k + 1]) { std::cerr << "payload buffer too small" << std::endl; exit(2); }
       const bool mapped = !(sizes[k] < sizes[k + 1]);  // codec.cpp:272-279
       const int pick = k + (mapped ? 1 : 0);
       f.framestats[ch].enc_mapped = mapped;

@@ -150,12 +150,18 @@ class FrameCoder {
       }
     }
     check_on(ctx, sacopt_encode_payloads(ctx, nbuf, src.data(), n.data(), mb.data(), used.data(), out.data(), cap.data(), sizes.data()));
+    for (int k = 0; k < nbuf; k++)  // incompressible data can need more than 4 bytes per sample: that buffer again, with the size the call reported
+      if (sizes[k] > cap[k]) {
+        cap[k] = sizes[k];
+        outs[k].resize((size_t)cap[k]);
+        out[k] = outs[k].data();
+        check_on(ctx, sacopt_encode_payloads(ctx, 1, &src[k], &n[k], &mb[k], &used[k], &out[k], &cap[k], &sizes[k]));
+      }
     for (int b = 0; b < nframes; b++) {
       FrameCoder &f = *fc[b];
       recs[b].numsamples = (uint32_t)f.numsamples;
       for (int ch = 0; ch < 2; ch++) {
         const int k = 4 * b + 2 * ch;
-        if (sizes[k] > cap[k] || sizes[k + 1] > cap[k + 1]) throw std::runtime_error("sacopt: payload buffer too small");
         const bool mapped = !(sizes[k] < sizes[k + 1]);
         const int pick = k + (mapped ? 1 : 0);
         f.enc_mapped[ch] = mapped;

@@ -370,7 +370,7 @@ class Context:
         self._ck(lib().sacopt_coded_sizes(self._h, nb, ptrs, _p(ns), _p(mb), _p(out)))
         return out
 
-    def encode_payloads(self, bufs, maxbpn, used=None):
+    def encode_payloads(self, bufs, maxbpn, used=None, cap=None):
         """sacopt_encode_payloads: the payload bytes of FrameCoder::EncodeMonoFrame_Normal (used[b] None) / _Mapped (used[b] =
         uint8[2*32769] Remap tables) for s2u buffers (numpy int32 arrays or (device pointer, n) tuples). Returns a list of bytes objects."""
         nb = len(bufs)
@@ -383,20 +383,28 @@ class Context:
                 a = np.ascontiguousarray(b, dtype=np.int32); keep.append(a)
                 ptrs[i] = a.ctypes.data if len(a) else None; ns[i] = len(a)
             else:   # (device pointer, n)
-                a = range(int(b[1]))
                 ptrs[i] = int(b[0]); ns[i] = int(b[1])
             u = None if used is None or used[i] is None else np.ascontiguousarray(used[i], dtype=np.uint8)
             if u is not None:
                 assert len(u) == 2 * 32769
                 keep.append(u)
             uptr[i] = None if u is None else u.ctypes.data
-            caps[i] = 4 * len(a) + 8192 + 64
+            caps[i] = 4 * int(ns[i]) + 8192 + 64 if cap is None else cap   # (cap: tests of the too-small-buffer path)
             o = np.zeros(caps[i], np.uint8); outs.append(o)
             optr[i] = o.ctypes.data
         mb = np.ascontiguousarray(maxbpn, dtype=np.int32)
         sizes = np.zeros(nb, np.int32)
         self._ck(lib().sacopt_encode_payloads(self._h, nb, ptrs, _p(ns), _p(mb), uptr, optr, _p(caps), _p(sizes)))
-        assert (sizes <= caps).all(), "payload larger than its buffer"
+        big = [i for i in range(nb) if sizes[i] > caps[i]]
+        if big:   # incompressible data can need more than 4 bytes per sample: those buffers again, with the size the first call reported
+            k = len(big)
+            p2, u2, o2 = (C.c_void_p * k)(), (C.c_void_p * k)(), (C.c_void_p * k)()
+            for j, i in enumerate(big):
+                outs[i] = np.zeros(int(sizes[i]), np.uint8)
+                p2[j], u2[j], o2[j] = ptrs[i], uptr[i], outs[i].ctypes.data
+            n2 = np.ascontiguousarray(ns[big]); m2 = np.ascontiguousarray(mb[big]); c2 = np.ascontiguousarray(sizes[big]); s2 = np.zeros(k, np.int32)
+            self._ck(lib().sacopt_encode_payloads(self._h, k, p2, _p(n2), _p(m2), u2, o2, _p(c2), _p(s2)))
+            assert (s2 == c2).all()
         return [outs[i][:sizes[i]].tobytes() for i in range(nb)]
 
     def cost_meanrms(self, buf):

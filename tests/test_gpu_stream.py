@@ -247,6 +247,8 @@ def test_encode_payloads_bytes_vs_restated_coder(oracle):
     with sacopt.Context(0) as c:
         got = c.encode_payloads(bufs, mb, used)
         sizes = c.coded_sizes([b for b, u in zip(bufs, used) if u is None], [m for m, u in zip(mb, used) if u is None])
+        # output buffers that are too small: the call reports the sizes, the binding asks again with them
+        assert c.encode_payloads(bufs[:6], mb[:6], used[:6], cap=10) == got[:6]
     k = 0
     for i, (b, m, u) in enumerate(zip(bufs, mb, used)):
         b = np.ascontiguousarray(b, dtype=np.int32)
