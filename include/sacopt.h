@@ -165,8 +165,9 @@ int sacopt_cost_meanrms(sacopt_ctx *ctx, const int32_t *buf, int n, double *cost
 /* ---- size of FrameCoder::EncodeMonoFrame_Normal's payload (src/codec.cpp:237-247): BitplaneCoder::Encode (src/coder/vle.cpp:110-138)
  * over RangeCoderSH (src/coder/range.cpp:52-90) -- SURVEY.md 8f.4 ------------------------------------------------------------
  * sizes[b] = the number of bytes the host's bit-plane coder writes for the s2u residuals s2u[b][0..n[b]) coded with maxbpn[b]
- * planes + 1 (framestats[ch].maxbpn, src/codec.cpp:207-208), exactly. One coder per GPU lane, so the call pays off for many
- * buffers at once (candidates x channels x frames); the bytes themselves stay the host coder's job. s2u: host array of nbuf
+ * planes + 1 (framestats[ch].maxbpn, src/codec.cpp:207-208), exactly. Every buffer is a coder of its own and all of a call's
+ * coders run at once (a workgroup each, up to 8192; a lane each beyond), so the call pays off for many buffers (candidates x
+ * channels x frames); the bytes themselves: sacopt_encode_payloads below. s2u: host array of nbuf
  * host-or-device pointers; n, maxbpn, sizes: host arrays. The coder's logistic tables (src/model/domain.h:12-23) are
  * tabulated with the libm of the host that created the context, as the reference's static initialiser does.
  * maxbpn[b] in 0..30. A value may have bits above plane maxbpn[b] (s2u of a residual beyond 2^30 wraps negative and the
