@@ -55,6 +55,7 @@ struct BpEmit {
   RcState *rc;          // mapped: where k_mapenc leaves the coder's state for k_bppipe<true>
   int32_t cap, pad;
 };
+static_assert(sizeof(RcState) == 24 && sizeof(BpEmit) == 32 && sizeof(BpJob) == 16, "layouts shared with sacopt.cpp");
 
 __device__ __forceinline__ int bp_clamp(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 __device__ __forceinline__ int bp_idiv32(int val, int s) { return val < 0 ? -(((-val) + (1 << (s - 1))) >> s) : (val + (1 << (s - 1))) >> s; }

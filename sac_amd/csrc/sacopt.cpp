@@ -65,6 +65,7 @@ int sacopt_launch_unpredict(int type, const UnJob *jobs, int njobs, const uint16
 struct BpJob { const int32_t *buf; int32_t n, maxbpn; };
 struct RcState { unsigned long long lowc; uint32_t range, ffnum, cache, pos; };
 struct BpEmit { uint8_t *out; const uint8_t *used; RcState *rc; int32_t cap, pad; };
+static_assert(sizeof(RcState) == 24 && sizeof(BpEmit) == 32 && sizeof(BpJob) == 16, "layouts shared with bitplane.h");
 extern "C" int sacopt_launch_payloads(const BpJob *jobs, const BpEmit *emit, int nbuf, const int32_t *which, int nmapped,
                                       const int16_t *fwd, const uint16_t *inv, const uint16_t *sse_init, int tscale, int xscale, int32_t *sizes,
                                       hipStream_t st);
