@@ -383,6 +383,12 @@ def test_reference_program_with_gpu_predictor(tmp_path, prof, flag):
                          stderr=subprocess.PIPE, text=True, timeout=300, env=benv)
     assert (tmp_path / "gpub.sac").read_bytes() == want
     assert 'sac_gpu_timing {' in out.stderr and '"batches": 2' in out.stderr
+    # ... and with FrameCoder::Encode taken from the device as well (sacopt_encode_payloads: both payload variants of every channel,
+    # the smaller kept): no host coder at all, the same file
+    out = subprocess.run([sac_gpu, "--encode", flag, str(wav), str(tmp_path / "gpud.sac")], check=True, stdout=subprocess.DEVNULL,
+                         stderr=subprocess.PIPE, text=True, timeout=300, env=dict(benv, SAC_GPU_DEVICE_CODER="1"))
+    assert (tmp_path / "gpud.sac").read_bytes() == want
+    assert '"device_coder": 1' in out.stderr
     run(sac, "--decode", str(tmp_path / "ref.sac"), str(tmp_path / "ref.wav"))
     run(sac_gpu, "--decode", str(tmp_path / "ref.sac"), str(tmp_path / "gpu.wav"))
     assert (tmp_path / "gpu.wav").read_bytes() == (tmp_path / "ref.wav").read_bytes()
